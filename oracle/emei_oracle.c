@@ -1,0 +1,373 @@
+/*
+ * emei_oracle.c — CPU restatement of the reference's env-step arithmetic.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; emei_amd/ never does.  It exists to check the
+ * HIP kernels and to be timed as the CPU baseline ("port").
+ *
+ * Parity status
+ *   - CartPole (classic control): PINNED.  Bit-compared against tests/golden/cartpole_golden.npz,
+ *     which oracle/gen_golden.py produced by running the unmodified reference files
+ *     (emei/envs/classic_control/{base_control,cartpole}.py) in the build container.
+ *   - InvertedPendulum reward/terminal/wrap/euler-position/noise helpers: PINNED by
+ *     tests/golden/mujoco_firstparty_golden.npz (same generator).
+ *   - InvertedPendulum *dynamics* (MuJoCo mj_step): PARITY UNPINNED.  The arithmetic lives in the
+ *     third-party `mujoco` package (requirements/main.txt:7, "mujoco >= 2.2.0", no lock, not
+ *     vendored, absent from the image).  What is restated here is MuJoCo's published algorithm for
+ *     this 2-DoF model (inertia-from-geom of the capsules in assets/inverted_pendulum.xml:12-23,
+ *     CRBA/RNE closed form, explicit Euler on qvel, the soft joint-limit constraint of the
+ *     "Computation" chapter) combined with emei's forward-Euler position override
+ *     (emei/envs/mujoco/mujoco_env.py:86-109, 169-195).
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * CartPole.  Variants: 0 = CartPoleSwingUp, 1 = CartPoleBalancing.
+ * Constants: emei/envs/classic_control/cartpole.py:22-31, SwingUp x_threshold :140.
+ * ---------------------------------------------------------------------------------------- */
+#define CP_GRAVITY 9.8
+#define CP_MASS_CART 1.0
+#define CP_MASS_POLE 0.1
+#define CP_LENGTH 0.5
+#define CP_FORCE_MAG 10.0
+
+/* cartpole.py:48-60 — evaluated in double (Python floats, math.sin/cos, ** 2 via pow), then
+ * rounded to float32 on return (np.array(..., dtype=np.float32)). */
+static void cp_dsdt(const double y[5], float d[5]) {
+    const double total_mass = CP_MASS_POLE + CP_MASS_CART; /* cartpole.py:25 */
+    double x_dot = y[1], theta = y[2], theta_dot = y[3], force = y[4];
+    double pole_mass_length = CP_MASS_POLE * CP_LENGTH;
+    double cos_theta = cos(theta);
+    double sin_theta = sin(theta);
+    double temp = (force + pole_mass_length * pow(theta_dot, 2.0) * sin_theta) / total_mass;
+    double theta_acc = (CP_GRAVITY * sin_theta - cos_theta * temp) /
+                       (CP_LENGTH * (4.0 / 3.0 - CP_MASS_POLE * pow(cos_theta, 2.0) / total_mass));
+    double x_acc = temp - pole_mass_length * theta_acc * cos_theta / total_mass;
+    d[0] = (float)x_dot;
+    d[1] = (float)x_acc;
+    d[2] = (float)theta_dot;
+    d[3] = (float)theta_acc;
+    d[4] = 0.0f;
+}
+
+/* base_control.py:133-173, "euler" branch (:162-164):  y += derivs(y) * dt.
+ * derivs(y) is float32, dt a Python float (weak scalar under NumPy 2 promotion), so the product is
+ * rounded to float32; the in-place add promotes it back to the float64 accumulator. */
+static void cp_ode_euler(double y[5], double dt, int steps) {
+    const float dt32 = (float)dt;
+    for (int s = 0; s < steps; ++s) {
+        float d[5];
+        cp_dsdt(y, d);
+        for (int i = 0; i < 5; ++i) {
+            volatile float inc = d[i] * dt32; /* volatile: forbid fusing/widening the f32 product */
+            y[i] += (double)inc;
+        }
+    }
+}
+
+static inline double cp_x_threshold(int variant) { return variant == 0 ? 5.0 : 2.4; }
+static inline double cp_theta_threshold(void) { return 12 * 2 * M_PI / 360; } /* cartpole.py:30 */
+
+/* cartpole.py:145-147 (SwingUp), :124-126 (Balancing): terminal = not(notdone); NaN => terminal. */
+static inline uint8_t cp_terminal(int variant, const double* obs) {
+    int notdone;
+    if (variant == 0)
+        notdone = fabs(obs[0]) < 5.0;
+    else
+        notdone = (fabs(obs[2]) < cp_theta_threshold()) & (fabs(obs[0]) < 2.4);
+    return (uint8_t)!notdone;
+}
+
+/* cartpole.py:149-151 (SwingUp): (cos(theta)+1)/2; :128-129 (Balancing): 1.0 */
+static inline double cp_reward(int variant, const double* obs) {
+    return variant == 0 ? (cos(obs[2]) + 1) / 2 : 1.0;
+}
+
+/* base_control.py:61-83 for a batch of independent envs.  state: [n,4] row-major float64, in/out.
+ * action: {0,1}; force = +force_mag if action == 1 else -force_mag (cartpole.py:121-122,142-143). */
+EXPORT void emei_oracle_cartpole_step(int variant, int64_t n, int freq_rate, double dt, double* state,
+                                      const int32_t* action, double* reward, uint8_t* terminal) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double y[5];
+        memcpy(y, state + 4 * i, 4 * sizeof(double));
+        y[4] = action[i] == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
+        cp_ode_euler(y, dt, freq_rate);
+        memcpy(state + 4 * i, y, 4 * sizeof(double));
+        reward[i] = cp_reward(variant, y);
+        terminal[i] = cp_terminal(variant, y);
+    }
+}
+
+EXPORT void emei_oracle_cartpole_reward(int variant, int64_t n, const double* obs, double* reward) {
+    for (int64_t i = 0; i < n; ++i) reward[i] = cp_reward(variant, obs + 4 * i);
+}
+
+EXPORT void emei_oracle_cartpole_terminal(int variant, int64_t n, const double* obs, uint8_t* terminal) {
+    for (int64_t i = 0; i < n; ++i) terminal[i] = cp_terminal(variant, obs + 4 * i);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * float32 "port" of the same step: the arithmetic the HIP kernel performs (float32 state,
+ * float32 derivative, unfused product-then-add), with libm sinf/cosf.  Used (a) to bound the
+ * float32-vs-reference error on the CPU before going to the GPU and (b) as the SoA CPU baseline.
+ * state: SoA float32 arrays x, xd, th, thd of length n.
+ * ---------------------------------------------------------------------------------------- */
+EXPORT void emei_oracle_cartpole_step_f32(int variant, int64_t n, int freq_rate, float dt, float* x, float* xd,
+                                          float* th, float* thd, const int32_t* action, float* reward,
+                                          uint8_t* terminal) {
+    const float total_mass = (float)(CP_MASS_POLE + CP_MASS_CART);
+    const float pml = (float)(CP_MASS_POLE * CP_LENGTH);
+    const float th_thr = (float)cp_theta_threshold();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        float X = x[i], XD = xd[i], TH = th[i], THD = thd[i];
+        float force = action[i] == 1 ? (float)CP_FORCE_MAG : -(float)CP_FORCE_MAG;
+        for (int s = 0; s < freq_rate; ++s) {
+            float c = cosf(TH), sn = sinf(TH);
+            float temp = (force + pml * (THD * THD) * sn) / total_mass;
+            float thacc = ((float)CP_GRAVITY * sn - c * temp) /
+                          ((float)CP_LENGTH * ((float)(4.0 / 3.0) - (float)CP_MASS_POLE * (c * c) / total_mass));
+            float xacc = temp - pml * thacc * c / total_mass;
+            volatile float i0 = XD * dt, i1 = xacc * dt, i2 = THD * dt, i3 = thacc * dt;
+            X += i0;
+            XD += i1;
+            TH += i2;
+            THD += i3;
+        }
+        x[i] = X, xd[i] = XD, th[i] = TH, thd[i] = THD;
+        if (variant == 0) {
+            reward[i] = (cosf(TH) + 1.0f) * 0.5f;
+            terminal[i] = (uint8_t)!(fabsf(X) < 5.0f);
+        } else {
+            reward[i] = 1.0f;
+            terminal[i] = (uint8_t)!((fabsf(TH) < th_thr) & (fabsf(X) < 2.4f));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Counter-based RNG used by the engine's *device-side* reset (perf mode, auto-reset).  The
+ * reference seeds PCG64 on the host (base_control.py:38-47; cartpole.py:153-156); that is what
+ * parity mode uploads.  The device generator is the build's own specification (Philox4x32-10,
+ * Salmon et al. 2011): key = 64-bit seed, counter = (env index lo, env index hi, episode, block).
+ * The oracle restates it so auto-reset rollouts can be checked bit-for-bit.
+ * ---------------------------------------------------------------------------------------- */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+EXPORT void emei_oracle_philox(uint64_t seed, uint64_t env, uint32_t episode, uint32_t block, uint32_t out[4]) {
+    uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), episode, block};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    memcpy(out, c, sizeof(c));
+}
+
+static inline float u01(uint32_t r) { return (float)(r >> 8) * 0x1.0p-24f; } /* [0,1) on a 2^-24 grid */
+
+/* U(-0.05, 0.05)^4, SwingUp adds pi to theta: the distribution of cartpole.py:131-132,153-156. */
+EXPORT void emei_oracle_cartpole_init_f32(int variant, uint64_t seed, uint64_t env, uint32_t episode, float s[4]) {
+    uint32_t r[4];
+    emei_oracle_philox(seed, env, episode, 0, r);
+    for (int i = 0; i < 4; ++i) {
+        volatile float sc = 0.1f * u01(r[i]);
+        s[i] = -0.05f + sc;
+    }
+    if (variant == 0) s[2] += (float)M_PI;
+}
+
+/* Box-Muller pair from two Philox words (device-side Gaussian init noise, mujoco_env.py:137-140
+ * distribution; the reference draws from the global numpy MT19937 stream on the host). */
+static inline void boxmuller(uint32_t a, uint32_t b, float* z0, float* z1) {
+    float u1 = ((float)(a >> 8) + 1.0f) * 0x1.0p-24f; /* (0,1] */
+    float u2 = u01(b);
+    float rad = sqrtf(-2.0f * logf(u1));
+    float ang = 6.283185307179586f * u2;
+    *z0 = rad * cosf(ang);
+    *z1 = rad * sinf(ang);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * InvertedPendulum (MuJoCo-backed; dynamics parity UNPINNED — see header).
+ * Variants: 0 ReboundBalancing, 1 BoundaryBalancing, 2 ReboundSwingUp, 3 BoundarySwingUp
+ * (emei/envs/mujoco/inverted_pendulum.py:52-183).
+ * Model constants from emei/envs/mujoco/assets/inverted_pendulum.xml:
+ *   gravity 9.81 (:8); slider range [-2,2] (:14); cart capsule r=.1 half-length .1 (:15);
+ *   hinge about +y, range +-90 deg (:17); pole capsule fromto (0,0,0)-(0.001,0,0.6) r=.049 (:18);
+ *   motor gear 100, ctrlrange [-3,3] (:23); default geom density 1000 (MuJoCo default).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double mc, mp, r, Icom, phi0; /* cart mass, pole mass, |com|, inertia about com (y), com angle */
+    double g, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
+    double invweight_slider; /* dof_invweight0 of the slider (at qpos0 of the compiled model) */
+    /* soft joint-limit constraint: default solref (0.02, 1), solimp (0.9, 0.95, 0.001, 0.5, 2) */
+    double timeconst, dampratio, dmin, dmax, width;
+} ip_model_t;
+
+static double capsule_mass(double rho, double r, double half) {
+    return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r);
+}
+/* inertia of a capsule about an axis through its centre, perpendicular to its long axis
+ * (cylinder + two hemispherical caps; the closed form MuJoCo's compiler uses for inertiafromgeom) */
+static double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half;
+    double mcyl = rho * M_PI * r * r * h;
+    double msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+
+EXPORT void emei_oracle_ip_model(ip_model_t* m) {
+    const double rho = 1000.0;
+    m->mc = capsule_mass(rho, 0.1, 0.1);
+    double fx = 0.001, fz = 0.6;
+    double len = sqrt(fx * fx + fz * fz);
+    m->mp = capsule_mass(rho, 0.049, len / 2);
+    m->Icom = capsule_inertia_perp(rho, 0.049, len / 2);
+    m->r = len / 2;
+    m->phi0 = atan2(fx, fz); /* com direction measured from +z towards +x (rotation about +y) */
+    m->g = 9.81;
+    m->gear = 100.0;
+    m->ctrl_lo = -3.0, m->ctrl_hi = 3.0;
+    m->x_lo = -2.0, m->x_hi = 2.0;
+    m->timeconst = 0.02, m->dampratio = 1.0, m->dmin = 0.9, m->dmax = 0.95, m->width = 0.001;
+    /* invweight0: (M^-1)_00 at qpos0 (theta = 0, pole upright in the compiled model) */
+    double c = cos(m->phi0);
+    double M11 = m->mc + m->mp, M12 = m->mp * m->r * c, M22 = m->Icom + m->mp * m->r * m->r;
+    m->invweight_slider = M22 / (M11 * M22 - M12 * M12);
+}
+
+EXPORT int emei_oracle_ip_model_size(void) { return (int)sizeof(ip_model_t); }
+
+static inline int ip_is_swingup(int variant) { return variant >= 2; }
+static inline int ip_is_rebound(int variant) { return (variant & 1) == 0; }
+
+/* One MuJoCo Euler substep + emei's position override (mujoco_env.py:91-97):
+ *   qacc at (q_old, v_old); v_new = v_old + dt*qacc; q_new = q_old + dt*v_old (:181,189-191). */
+static void ip_substep(const ip_model_t* m, int variant, double dt, double q[2], double v[2], double u) {
+    /* SwingUp's _update_model (inverted_pendulum.py:135-137,170-172) turns the pole body by pi about y */
+    double phi = q[1] + m->phi0 + (ip_is_swingup(variant) ? M_PI : 0.0);
+    double s = sin(phi), c = cos(phi);
+    double M11 = m->mc + m->mp, M12 = m->mp * m->r * c, M22 = m->Icom + m->mp * m->r * m->r;
+    double ctrl = u < m->ctrl_lo ? m->ctrl_lo : (u > m->ctrl_hi ? m->ctrl_hi : u);
+    double f1 = m->gear * ctrl + m->mp * m->r * s * v[1] * v[1];
+    double f2 = m->mp * m->g * m->r * s;
+    double det = M11 * M22 - M12 * M12;
+    double a0 = (M22 * f1 - M12 * f2) / det; /* unconstrained ("smooth") accelerations */
+    double a1 = (M11 * f2 - M12 * f1) / det;
+    /* Soft slider-limit constraint.  Boundary variants terminate as soon as x leaves (x_lo, x_hi)
+     * (inverted_pendulum.py:106-111,179-183) but MuJoCo still applies the limit force while the
+     * reference keeps stepping, so it is evaluated for every variant. */
+    double dist = 0, J = 0;
+    if (q[0] - m->x_lo < 0)
+        dist = q[0] - m->x_lo, J = 1.0;
+    else if (m->x_hi - q[0] < 0)
+        dist = m->x_hi - q[0], J = -1.0;
+    if (J != 0.0) {
+        double tc = m->timeconst < 2 * dt ? 2 * dt : m->timeconst; /* refsafe */
+        double xx = fabs(dist) / m->width;
+        double y = xx >= 1 ? 1.0 : (xx <= 0.5 ? 2 * xx * xx : 1 - 2 * (1 - xx) * (1 - xx));
+        double imp = m->dmin + y * (m->dmax - m->dmin);
+        double K = 1.0 / (m->dmax * m->dmax * tc * tc * m->dampratio * m->dampratio);
+        double B = 2.0 / (m->dmax * tc);
+        double aref = -B * (J * v[0]) - K * imp * dist;
+        double A = M22 / det; /* J M^-1 J^T, J = +-e_0 */
+        double R = (1 - imp) / imp * m->invweight_slider;
+        double force = (aref - J * a0) / (A + R);
+        if (force > 0) {
+            a0 += (M22 / det) * J * force;
+            a1 += (-M12 / det) * J * force;
+        }
+    }
+    double qn0 = q[0] + dt * v[0], qn1 = q[1] + dt * v[1];
+    v[0] += dt * a0;
+    v[1] += dt * a1;
+    q[0] = qn0, q[1] = qn1;
+}
+
+/* inverted_pendulum.py:45-49: theta_obs = (theta + pi) % (2 pi) - pi  (Python/NumPy floored mod) */
+static inline double ip_wrap(double th) {
+    double a = th + M_PI, p = 2 * M_PI;
+    double mod = fmod(a, p);
+    if (mod != 0 && ((mod < 0) != (p < 0))) mod += p;
+    return mod - M_PI;
+}
+
+static inline int ip_finite4(const double* o) { return isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(o[3]); }
+
+/* inverted_pendulum.py:73-79,103-111,139-146,174-183 */
+static inline double ip_reward(int variant, const double* obs) {
+    return ip_is_swingup(variant) ? (1 - cos(obs[1])) / 2 : 1.0;
+}
+static inline uint8_t ip_terminal(const ip_model_t* m, int variant, const double* obs) {
+    double y = cos(obs[1]), x = obs[0];
+    int fin = ip_finite4(obs);
+    int inx = (m->x_lo < x) && (x < m->x_hi);
+    int notdone;
+    switch (variant) {
+        case 0: notdone = (y >= 0.9) & fin; break;
+        case 1: notdone = (y >= 0) & inx & fin; break;
+        case 2: notdone = fin; break;
+        default: notdone = inx & fin; break;
+    }
+    return (uint8_t)!notdone;
+}
+
+EXPORT void emei_oracle_ip_reward(int variant, int64_t n, const double* obs, double* reward) {
+    for (int64_t i = 0; i < n; ++i) reward[i] = ip_reward(variant, obs + 4 * i);
+}
+EXPORT void emei_oracle_ip_terminal(int variant, int64_t n, const double* obs, uint8_t* terminal) {
+    ip_model_t m;
+    emei_oracle_ip_model(&m);
+    for (int64_t i = 0; i < n; ++i) terminal[i] = ip_terminal(&m, variant, obs + 4 * i);
+}
+EXPORT void emei_oracle_ip_wrap(int64_t n, const double* th, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = ip_wrap(th[i]);
+}
+
+/* mujoco_env.py:157-167 for a batch.  state [n,4] = (x, theta, v, omega) with theta UNWRAPPED (the
+ * internal qpos, inverted_pendulum.py:45-49 wraps only the observation); obs [n,4] is written
+ * with the wrapped angle; action [n] float64. */
+EXPORT void emei_oracle_ip_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
+                                double* obs, double* reward, uint8_t* terminal) {
+    ip_model_t m;
+    emei_oracle_ip_model(&m);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double q[2] = {state[4 * i], state[4 * i + 1]}, v[2] = {state[4 * i + 2], state[4 * i + 3]};
+        for (int s = 0; s < freq_rate; ++s) ip_substep(&m, variant, dt, q, v, action[i]);
+        state[4 * i] = q[0], state[4 * i + 1] = q[1], state[4 * i + 2] = v[0], state[4 * i + 3] = v[1];
+        double o[4] = {q[0], ip_wrap(q[1]), v[0], v[1]};
+        memcpy(obs + 4 * i, o, sizeof(o));
+        reward[i] = ip_reward(variant, o);
+        terminal[i] = ip_terminal(&m, variant, o);
+    }
+}
+
+/* Device-side init for InvertedPendulum: zeros + sigma * N(0,1) i.i.d. per coordinate (the
+ * distribution SURVEY 8d config 3 prescribes; the reference's row-slicing quirk, mujoco_env.py:243-244,
+ * is reproduced on the host path instead). */
+EXPORT void emei_oracle_ip_init_f32(uint64_t seed, uint64_t env, uint32_t episode, float sigma, float s[4]) {
+    uint32_t r[4];
+    emei_oracle_philox(seed, env, episode, 0, r);
+    float z[4];
+    boxmuller(r[0], r[1], &z[0], &z[1]);
+    boxmuller(r[2], r[3], &z[2], &z[3]);
+    for (int i = 0; i < 4; ++i) s[i] = sigma * z[i];
+}

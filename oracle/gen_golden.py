@@ -1,0 +1,409 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ from the *real* reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container, where the read-only
+reference checkout lives at /root/reference; the GPU box never sees the reference and
+only consumes the small ``.npz`` files this script writes.
+
+How the reference is imported: ``import emei`` pulls third-party
+packages that are absent offline (gym, h5py, pygame, mujoco).  The arithmetic on the
+classic-control path (``emei/envs/classic_control/{base_control,cartpole}.py``,
+``emei/core.py``) and the reward/terminal/euler-position/noise/graph helpers of the
+MuJoCo-backed classes is entirely first-party numpy/math, so we register inert
+``sys.modules`` stand-ins for the *plumbing* of those packages (a ``gym.Env`` that seeds
+``np_random`` exactly like gym 0.26 = ``Generator(PCG64(SeedSequence(seed)))``,
+``spaces.Discrete/Box``, no-op ``register``) and import the unmodified reference files
+from where they lie.  Nothing from the reference is copied; only inputs and the outputs
+the reference computed are stored.
+
+MuJoCo's ``mj_step`` itself is NOT available (no libmujoco in the image) so next-state
+vectors of the MuJoCo-backed bodies are not generated here: parity of those dynamics is
+"unpinned" (see DESIGN.md).  What *is* generated for them are the first-party pieces:
+reward/terminal functions, the forward-Euler position rule, the angle wrap, the
+init-noise routine and the transition-graph closure, called as unbound methods on a
+minimal stand-in ``self``.
+
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import math
+import os
+import sys
+import types
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+
+
+# --------------------------------------------------------------------------- stubs
+def _install_plumbing_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Env:
+        """gym 0.26 ``Env``: only the seeding behaviour of ``reset`` matters here."""
+
+        _np_random = None
+        metadata = {}
+
+        @property
+        def np_random(self):
+            if self._np_random is None:
+                self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence()))
+            return self._np_random
+
+        @np_random.setter
+        def np_random(self, v):
+            self._np_random = v
+
+        def reset(self, *, seed=None, options=None):
+            if seed is not None:
+                self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+    class Space:
+        def __init__(self, shape=(), dtype=None):
+            self.shape, self.dtype = tuple(shape), dtype
+
+    class Discrete(Space):
+        def __init__(self, n):
+            super().__init__((), np.int64)
+            self.n = int(n)
+
+        def contains(self, x):
+            if isinstance(x, int):
+                v = x
+            elif isinstance(x, (np.generic, np.ndarray)) and np.issubdtype(np.asarray(x).dtype, np.integer) and np.asarray(x).shape == ():
+                v = int(x)
+            else:
+                return False
+            return 0 <= v < self.n
+
+    class Box(Space):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            low = np.asarray(low, dtype=dtype)
+            high = np.asarray(high, dtype=dtype)
+            if shape is None:
+                shape = low.shape
+            super().__init__(shape, dtype)
+            self.low = np.broadcast_to(low, shape)
+            self.high = np.broadcast_to(high, shape)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    class EzPickle:
+        def __init__(self, *a, **k):
+            pass
+
+    class MujocoEnv(Env):
+        def __init__(self, *a, **k):
+            raise RuntimeError("MuJoCo is not available offline; construct nothing MuJoCo-backed")
+
+    class DependencyNotInstalled(Exception):
+        pass
+
+    gym = mod("gym", Env=Env)
+    gym.spaces = mod("gym.spaces", Space=Space, Discrete=Discrete, Box=Box)
+    gym.logger = mod("gym.logger", warn=lambda *a, **k: None)
+    gym.error = mod("gym.error", DependencyNotInstalled=DependencyNotInstalled)
+    gym.utils = mod("gym.utils", EzPickle=EzPickle)
+    gym.envs = mod("gym.envs")
+    gym.envs.registration = mod(
+        "gym.envs.registration",
+        registry={},
+        register=lambda **k: None,
+        make=lambda *a, **k: None,
+        spec=lambda *a, **k: None,
+        load_env_plugins=lambda *a, **k: None,
+    )
+    gym.envs.mujoco = mod("gym.envs.mujoco")
+    gym.envs.mujoco.mujoco_env = mod("gym.envs.mujoco.mujoco_env", MujocoEnv=MujocoEnv)
+    gym.wrappers = mod("gym.wrappers")
+    mod("h5py", Dataset=type("Dataset", (), {}), File=None)
+    pg = mod("pygame")
+    pg.gfxdraw = mod("pygame.gfxdraw")
+    mod("mujoco")
+
+
+def import_reference(ref_root):
+    _install_plumbing_stubs()
+    sys.path.insert(0, ref_root)
+    import emei  # noqa: F401  (the unmodified reference package)
+    from emei.envs.classic_control import cartpole as cp
+    from emei.envs.mujoco import inverted_pendulum as ip
+    from emei.envs.mujoco import half_cheetah as hc
+    from emei.envs.mujoco import mujoco_env as me
+    from emei import core
+
+    return NS(cp=cp, ip=ip, hc=hc, me=me, core=core)
+
+
+# --------------------------------------------------------------------------- inputs
+def wide_states(rng, n, swingup):
+    """States covering the regimes the envs visit plus threshold/NaN/Inf rows."""
+    s = np.empty((n, 4))
+    s[:, 0] = rng.uniform(-6.0, 6.0, n)
+    s[:, 1] = rng.normal(0.0, 3.0, n)
+    s[:, 2] = rng.uniform(-4 * math.pi, 4 * math.pi, n) if swingup else rng.uniform(-0.45, 0.45, n)
+    s[:, 3] = rng.normal(0.0, 6.0, n)
+    k = n // 8
+    # tight initial-state-like rows
+    s[:k] = rng.uniform(-0.05, 0.05, (k, 4))
+    if swingup:
+        s[:k, 2] += math.pi
+    # rows that land near the terminal thresholds after one step
+    thr = 5.0 if swingup else 2.4
+    s[k : 2 * k, 0] = np.sign(rng.standard_normal(k)) * (thr + rng.uniform(-0.2, 0.2, k))
+    if not swingup:
+        th = 12 * 2 * math.pi / 360
+        s[2 * k : 3 * k, 2] = np.sign(rng.standard_normal(k)) * (th + rng.uniform(-0.05, 0.05, k))
+        s[2 * k : 3 * k, 0] = rng.uniform(-1.0, 1.0, k)
+    # large spinning angles (SwingUp spins for hundreds of radians)
+    if swingup:
+        s[3 * k : 4 * k, 2] = rng.uniform(-600.0, 600.0, k)
+        s[3 * k : 4 * k, 3] = rng.normal(0.0, 15.0, k)
+    # non-finite rows
+    s[-1] = [np.nan, 0.1, 0.2, 0.3]
+    s[-2] = [0.1, np.inf, 0.2, 0.3]
+    s[-3] = [0.1, 0.2, np.nan, 0.3]
+    s[-4] = [-np.inf, 0.2, 0.1, 0.3]
+    s[-5] = [0.1, 0.2, 0.3, -np.inf]
+    return s
+
+
+def gen_cartpole(ref, out):
+    envs = {"swingup": ref.cp.CartPoleSwingUpEnv, "balancing": ref.cp.CartPoleBalancingEnv}
+    data = {}
+    rng = np.random.default_rng(20240)
+
+    # (A) one-step pairs over a wide state distribution -------------------------------
+    n = 1024
+    for name, cls in envs.items():
+        s0 = wide_states(rng, n, name == "swingup")
+        act = rng.integers(2, size=n)
+        data[f"onestep_{name}_state"] = s0
+        data[f"onestep_{name}_action"] = act.astype(np.int64)
+        for fr, dt in ((1, 0.02), (4, 0.02), (2, 0.01)):
+            env = cls(freq_rate=fr, real_time_scale=dt)
+            env.reset(seed=0)
+            nxt = np.empty((n, 4))
+            rew = np.empty(n)
+            term = np.empty(n, dtype=bool)
+            raised = np.zeros(n, dtype=bool)
+            with np.errstate(all="ignore"):
+                for i in range(n):
+                    env.state = s0[i].copy()
+                    try:
+                        o, r, t, tr, info = env.step(int(act[i]))
+                    except (ValueError, OverflowError):
+                        # math.cos(+-inf) raises "math domain error" (cartpole.py:52): the reference
+                        # has no result for this row; recorded so the parity tests skip it.
+                        raised[i] = True
+                        nxt[i], rew[i], term[i] = np.nan, np.nan, True
+                        continue
+                    assert tr is False and info == {}
+                    nxt[i], rew[i], term[i] = o, r, t
+            tag = f"onestep_{name}_fr{fr}_dt{dt}"
+            data[tag + "_raised"] = raised
+            data[tag + "_next"] = nxt
+            data[tag + "_reward"] = rew
+            data[tag + "_terminal"] = term
+
+    # (B) seeded 1000-step open-loop trajectories (no reset after terminal: the reference
+    #     keeps integrating, base_control.py:61-83) ---------------------------------------
+    T = 1000
+    for name, cls in envs.items():
+        for fr in (1, 4):
+            for seed in range(4):
+                env = cls(freq_rate=fr, real_time_scale=0.02)
+                o0, info = env.reset(seed=seed)
+                acts = np.random.default_rng(1000 + seed).integers(2, size=T)
+                traj = np.empty((T + 1, 4))
+                rew = np.empty(T)
+                term = np.empty(T, dtype=bool)
+                traj[0] = o0
+                with np.errstate(all="ignore"):
+                    for t in range(T):
+                        o, r, d, _, _ = env.step(int(acts[t]))
+                        traj[t + 1], rew[t], term[t] = o, r, d
+                tag = f"traj_{name}_fr{fr}_seed{seed}"
+                data[tag + "_actions"] = acts.astype(np.int64)
+                data[tag + "_states"] = traj
+                data[tag + "_reward"] = rew
+                data[tag + "_terminal"] = term
+
+    # (C) reset / batch init states -----------------------------------------------------
+    for name, cls in envs.items():
+        rs = []
+        for seed in range(16):
+            env = cls()
+            o, _ = env.reset(seed=seed)
+            rs.append(o)
+        data[f"reset_{name}_seeds0_15"] = np.asarray(rs)
+        env = cls()
+        env.reset(seed=7)
+        data[f"batchinit_{name}_seed7_B8"] = env.get_batch_init_state(8)
+        env.reset(seed=7)
+        data[f"batchinitobs_{name}_seed7_B8"] = env.get_batch_init_obs(8)
+
+    # (D) stand-alone batched reward / terminal ----------------------------------------
+    B = 512
+    for name, cls in envs.items():
+        env = cls()
+        obs = wide_states(rng, B, name == "swingup")
+        thr = 5.0 if name == "swingup" else 2.4
+        # exact-threshold rows: strict '<' must classify them terminal
+        obs[10, 0] = thr
+        obs[11, 0] = -thr
+        obs[12, 0] = np.nextafter(thr, 0.0)
+        obs[13, 0] = np.nextafter(thr, 10.0)
+        if name == "balancing":
+            th = env.theta_threshold_radians
+            obs[10:14, 0] = 0.0
+            obs[14, 2], obs[14, 0] = th, 0.0
+            obs[15, 2], obs[15, 0] = -th, 0.0
+            obs[16, 2], obs[16, 0] = np.nextafter(th, 0.0), 0.0
+            obs[17, 0], obs[17, 2] = 2.4, 0.0
+            obs[18, 0], obs[18, 2] = np.nextafter(2.4, 0.0), 0.0
+        with np.errstate(all="ignore"):
+            data[f"batch_{name}_obs"] = obs
+            data[f"batch_{name}_reward"] = np.asarray(env.get_batch_reward(obs), dtype=np.float64)
+            data[f"batch_{name}_terminal"] = env.get_batch_terminal(obs)
+        data[f"const_{name}_x_threshold"] = np.float64(env.x_threshold)
+        data[f"const_{name}_theta_threshold"] = np.float64(env.theta_threshold_radians)
+
+    np.savez_compressed(os.path.join(out, "cartpole_golden.npz"), **data)
+    return data
+
+
+def gen_mujoco_firstparty(ref, out):
+    """First-party helpers of the MuJoCo-backed classes, called unbound on a stand-in self."""
+    data = {}
+    rng = np.random.default_rng(777)
+    ip = ref.ip
+    jnt_range = np.array([[-2.0, 2.0], [-math.pi / 2, math.pi / 2]])  # assets/inverted_pendulum.xml:14,17
+    fake = NS(model=NS(jnt_range=jnt_range))
+    B = 512
+    obs = np.empty((B, 4))
+    obs[:, 0] = rng.uniform(-2.5, 2.5, B)
+    obs[:, 1] = rng.uniform(-math.pi, math.pi, B)
+    obs[:, 2] = rng.normal(0, 3, B)
+    obs[:, 3] = rng.normal(0, 6, B)
+    obs[0, 0], obs[1, 0] = 2.0, -2.0
+    obs[2, 0], obs[3, 0] = np.nextafter(2.0, 0.0), np.nextafter(-2.0, 0.0)
+    obs[4, 1] = math.acos(0.9)
+    obs[5, 1] = math.pi / 2
+    obs[6, 1] = -math.pi / 2
+    obs[7] = [0.0, 0.0, np.nan, 0.0]
+    obs[8] = [0.0, 0.0, 0.0, np.inf]
+    obs[9] = [np.nan, 0.0, 0.0, 0.0]
+    obs[10] = [0.0, np.inf, 0.0, 0.0]
+    obs[11] = [0.0, 0.0, 0.0, 0.0]
+    data["ip_obs"] = obs
+    with np.errstate(all="ignore"):
+        for nm, cls in (
+            ("rebound_balancing", ip.ReboundInvertedPendulumBalancingEnv),
+            ("boundary_balancing", ip.BoundaryInvertedPendulumBalancingEnv),
+            ("rebound_swingup", ip.ReboundInvertedPendulumSwingUpEnv),
+            ("boundary_swingup", ip.BoundaryInvertedPendulumSwingUpEnv),
+        ):
+            data[f"ip_{nm}_reward"] = np.asarray(cls.get_batch_reward(fake, obs), dtype=np.float64)
+            data[f"ip_{nm}_terminal"] = cls.get_batch_terminal(fake, obs)
+
+    # angle wrap of current_obs (inverted_pendulum.py:45-49)
+    sv = np.column_stack(
+        [rng.uniform(-2, 2, 256), rng.uniform(-40, 40, 256), rng.normal(0, 3, 256), rng.normal(0, 6, 256)]
+    )
+    sv[0, 1], sv[1, 1], sv[2, 1], sv[3, 1] = math.pi, -math.pi, 3 * math.pi, 0.0
+    wrapped = np.empty_like(sv)
+    for i in range(len(sv)):
+        f = NS(state_vector=lambda i=i: sv[i])
+        wrapped[i] = ip.BaseInvertedPendulumEnv.current_obs.fget(f)
+    data["ip_wrap_in"] = sv
+    data["ip_wrap_out"] = wrapped
+
+    # transition graph + closure (core.py:142-161; graph inverted_pendulum.py:39-41)
+    g = np.array([[0, 0, 0, 0], [0, 0, 1, 1], [1, 0, 0, 0], [0, 1, 1, 1], [0, 0, 1, 1]])
+    f = NS(_transition_graph=g, observation_space=NS(shape=(4,)), action_space=NS(shape=(1,)))
+    for rt in (1, 2, 3, 5):
+        data[f"ip_graph_repeat{rt}"] = np.asarray(ref.core.EmeiEnv.get_transition_graph(f, rt))
+
+    # forward-Euler position rule (mujoco_env.py:169-195), slide=2 / hinge=3 joints
+    for nm, nq in (("ip", 2), ("cheetah", 9)):
+        jt = [2, 3] if nq == 2 else [2, 2, 3, 3, 3, 3, 3, 3, 3]
+        for dt in (0.02, 0.002):
+            f = NS(model=NS(jnt_type=jt), real_time_scale=dt)
+            qp = rng.normal(0, 1, (64, nq))
+            qv = rng.normal(0, 5, (64, nq))
+            newp = np.stack([ref.me.EmeiMujocoEnv.get_euler_pos(f, qp[i], qv[i]) for i in range(64)])
+            data[f"euler_{nm}_dt{dt}_qpos"] = qp
+            data[f"euler_{nm}_dt{dt}_qvel"] = qv
+            data[f"euler_{nm}_dt{dt}_newpos"] = newp
+
+    # init-noise routine for B=1 (mujoco_env.py:197-249); global np.random, legacy MT19937
+    for nm, nq, sig in (("ip", 2, 5e-3), ("cheetah", 9, 0.1)):
+        jt = [2, 3] if nq == 2 else [2, 2, 3, 3, 3, 3, 3, 3, 3]
+        f = NS(model=NS(jnt_type=jt))
+        outs_p, outs_v = [], []
+        for seed in range(8):
+            np.random.seed(seed)
+            p, v = ref.me.EmeiMujocoEnv.additive_gaussian_noise(f, np.zeros((1, nq)), np.zeros((1, nq)), sig)
+            outs_p.append(p[0])
+            outs_v.append(v[0])
+        data[f"noise_{nm}_pos_seeds0_7"] = np.asarray(outs_p)
+        data[f"noise_{nm}_vel_seeds0_7"] = np.asarray(outs_v)
+
+    # HalfCheetah reward / terminal (half_cheetah.py:59-67); dt = timestep*frame_skip (gym MujocoEnv.dt)
+    hc = ref.hc
+    f = NS(_forward_reward_weight=1.0, _ctrl_cost_weight=0.1, dt=0.002 * 4)
+    Bc = 256
+    o = rng.normal(0, 1, (Bc, 18))
+    po = o + rng.normal(0, 0.01, (Bc, 18))
+    a = rng.uniform(-1, 1, (Bc, 6))
+    o[3, 5] = np.nan
+    o[4, 17] = np.inf
+    # step() semantics: B = 1 per call (the batch form sums the control cost over the whole batch)
+    r1 = np.stack([hc.HalfCheetahRunningEnv.get_batch_reward(f, o[i : i + 1], po[i : i + 1], a[i : i + 1])[0, 0] for i in range(Bc)])
+    with np.errstate(all="ignore"):
+        data["cheetah_obs"] = o
+        data["cheetah_pre_obs"] = po
+        data["cheetah_action"] = a
+        data["cheetah_reward_B1"] = r1
+        data["cheetah_reward_batchquirk"] = hc.HalfCheetahRunningEnv.get_batch_reward(f, o, po, a)
+        data["cheetah_terminal"] = hc.HalfCheetahRunningEnv.get_batch_terminal(f, o)
+
+    # env_params_name string KAT (core.py:56-58; test/test_core.py:9-14)
+    names = []
+    for params in ({"a": 3, "b": 5, "d": 0.33, "c": "c"}, dict(freq_rate=1, real_time_scale=0.02), dict(freq_rate=4, real_time_scale=0.002, integrator="euler")):
+        names.append(ref.core.OfflineEnv.env_params_name.fget(NS(env_params=params)))
+    data["env_params_names"] = np.asarray(names)
+
+    np.savez_compressed(os.path.join(out, "mujoco_firstparty_golden.npz"), **data)
+    return data
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    ref = import_reference(a.ref)
+    c = gen_cartpole(ref, a.out)
+    m = gen_mujoco_firstparty(ref, a.out)
+    env = ref.cp.CartPoleSwingUpEnv()
+    o, _ = env.reset(seed=0)
+    print("reset(seed=0):", o)
+    for act in (0, 1, 1):
+        print(env.step(act)[:3])
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m))
+
+
+if __name__ == "__main__":
+    main()

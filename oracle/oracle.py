@@ -1,0 +1,199 @@
+"""ctypes front-end of the C oracle plus a NumPy restatement of the CartPole step.
+
+TEST INFRASTRUCTURE ONLY — never imported by emei_amd/.  Parity status: CartPole pinned by
+tests/golden/cartpole_golden.npz; MuJoCo-backed dynamics unpinned (see emei_oracle.c header).
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libemei_oracle.so")
+_lib = None
+
+CARTPOLE_VARIANTS = {"swingup": 0, "balancing": 1}
+IP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup": 2, "boundary_swingup": 3}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no GPU needed)."""
+    src = os.path.join(_HERE, "emei_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.emei_oracle_ip_model_size.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# --------------------------------------------------------------------------- CartPole (C)
+def cartpole_step(variant, state, action, freq_rate=1, dt=0.02):
+    """state [n,4] float64 (copied), action [n] int -> (next_state, reward, terminal)."""
+    v = CARTPOLE_VARIANTS[variant]
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
+    n = st.shape[0]
+    act = np.ascontiguousarray(action, dtype=np.int32).reshape(n)
+    rew = np.empty(n, np.float64)
+    term = np.empty(n, np.uint8)
+    lib().emei_oracle_cartpole_step(
+        C.c_int(v), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+        _p(st, C.c_double), _p(act, C.c_int32), _p(rew, C.c_double), _p(term, C.c_uint8))
+    return st, rew, term.astype(bool)
+
+
+def cartpole_rollout(variant, state0, actions, freq_rate=1, dt=0.02):
+    """Open-loop rollout without reset (base_control.py:61-83 never resets).
+    actions [T,n] -> states [T+1,n,4], reward [T,n], terminal [T,n]."""
+    st = np.array(state0, dtype=np.float64).reshape(-1, 4)
+    T = len(actions)
+    states = np.empty((T + 1,) + st.shape)
+    rew = np.empty((T, st.shape[0]))
+    term = np.empty((T, st.shape[0]), bool)
+    states[0] = st
+    for t in range(T):
+        st, rew[t], term[t] = cartpole_step(variant, st, actions[t], freq_rate, dt)
+        states[t + 1] = st
+    return states, rew, term
+
+
+def cartpole_step_f32(variant, soa, action, freq_rate=1, dt=0.02):
+    """float32 SoA port (the arithmetic of the HIP kernel, libm sinf/cosf). soa: 4 arrays, updated in place."""
+    v = CARTPOLE_VARIANTS[variant]
+    n = soa[0].shape[0]
+    act = np.ascontiguousarray(action, dtype=np.int32).reshape(n)
+    rew = np.empty(n, np.float32)
+    term = np.empty(n, np.uint8)
+    lib().emei_oracle_cartpole_step_f32(
+        C.c_int(v), C.c_int64(n), C.c_int(int(freq_rate)), C.c_float(float(dt)),
+        *[_p(a, C.c_float) for a in soa], _p(act, C.c_int32), _p(rew, C.c_float), _p(term, C.c_uint8))
+    return rew, term.astype(bool)
+
+
+def cartpole_reward(variant, obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 4)
+    out = np.empty(obs.shape[0])
+    lib().emei_oracle_cartpole_reward(C.c_int(CARTPOLE_VARIANTS[variant]), C.c_int64(len(out)), _p(obs, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def cartpole_terminal(variant, obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 4)
+    out = np.empty(obs.shape[0], np.uint8)
+    lib().emei_oracle_cartpole_terminal(C.c_int(CARTPOLE_VARIANTS[variant]), C.c_int64(len(out)), _p(obs, C.c_double), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
+def cartpole_init_state_host(variant, seed, batch_size):
+    """Reference reset distribution on the host: gym 0.26 np_random = Generator(PCG64(SeedSequence(seed)))
+    (base_control.py:38-47) -> uniform(-0.05, 0.05, (B,4)), SwingUp adds pi to theta (cartpole.py:131-132,153-156)."""
+    s = np.random.default_rng(seed).uniform(low=-0.05, high=0.05, size=(batch_size, 4))
+    if variant == "swingup":
+        s[:, 2] += np.pi
+    return s
+
+
+def philox(seed, env, episode, block=0):
+    out = (C.c_uint32 * 4)()
+    lib().emei_oracle_philox(C.c_uint64(seed), C.c_uint64(env), C.c_uint32(episode), C.c_uint32(block), out)
+    return np.array(out[:], dtype=np.uint32)
+
+
+def cartpole_init_f32(variant, seed, env, episode):
+    out = (C.c_float * 4)()
+    lib().emei_oracle_cartpole_init_f32(C.c_int(CARTPOLE_VARIANTS[variant]), C.c_uint64(seed), C.c_uint64(env), C.c_uint32(episode), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def ip_init_f32(seed, env, episode, sigma):
+    out = (C.c_float * 4)()
+    lib().emei_oracle_ip_init_f32(C.c_uint64(seed), C.c_uint64(env), C.c_uint32(episode), C.c_float(sigma), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+# --------------------------------------------------------------------------- CartPole (NumPy)
+def cartpole_step_numpy(variant, state, action, freq_rate=1, dt=0.02):
+    """Vectorised NumPy restatement of base_control.py:61-83 + cartpole.py:48-60: float64 state,
+    derivative rounded to float32, float32 product with float32(dt), float64 accumulate."""
+    y = np.array(state, dtype=np.float64).reshape(-1, 4).copy()
+    force = np.where(np.asarray(action).reshape(-1) == 1, 10.0, -10.0)
+    total_mass, pml = 0.1 + 1.0, 0.1 * 0.5
+    dt32 = np.float32(dt)
+    with np.errstate(all="ignore"):
+        for _ in range(freq_rate):
+            x_dot, theta, theta_dot = y[:, 1], y[:, 2], y[:, 3]
+            # math.sin/cos of the reference are libm; np.sin/cos may differ in the last ulp, which the
+            # float32 rounding of the derivative absorbs except at rare rounding boundaries.
+            c, s = np.cos(theta), np.sin(theta)
+            temp = (force + pml * theta_dot**2 * s) / total_mass
+            theta_acc = (9.8 * s - c * temp) / (0.5 * (4.0 / 3.0 - 0.1 * c**2 / total_mass))
+            x_acc = temp - pml * theta_acc * c / total_mass
+            d = np.stack([x_dot, x_acc, theta_dot, theta_acc], axis=1).astype(np.float32)
+            y += (d * dt32).astype(np.float64)
+        if variant == "swingup":
+            rew = (np.cos(y[:, 2]) + 1) / 2
+            term = ~(np.abs(y[:, 0]) < 5)
+        else:
+            rew = np.ones(len(y))
+            term = ~((np.abs(y[:, 2]) < 12 * 2 * math.pi / 360) & (np.abs(y[:, 0]) < 2.4))
+    return y, rew, term
+
+
+# --------------------------------------------------------------------------- InvertedPendulum (C)
+class IPModel(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "mc", "mp", "r", "Icom", "phi0", "g", "gear", "ctrl_lo", "ctrl_hi", "x_lo", "x_hi",
+        "invweight_slider", "timeconst", "dampratio", "dmin", "dmax", "width")]
+
+
+def ip_model():
+    m = IPModel()
+    assert C.sizeof(m) == lib().emei_oracle_ip_model_size()
+    lib().emei_oracle_ip_model(C.byref(m))
+    return m
+
+
+def ip_step(variant, state, action, freq_rate=1, dt=0.02):
+    """state [n,4]=(x, theta_unwrapped, v, omega) float64 -> (next_state, obs(wrapped), reward, terminal)."""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
+    n = st.shape[0]
+    act = np.ascontiguousarray(action, dtype=np.float64).reshape(n)
+    obs = np.empty((n, 4))
+    rew = np.empty(n)
+    term = np.empty(n, np.uint8)
+    lib().emei_oracle_ip_step(C.c_int(IP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+                              _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    return st, obs, rew, term.astype(bool)
+
+
+def ip_reward(variant, obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 4)
+    out = np.empty(obs.shape[0])
+    lib().emei_oracle_ip_reward(C.c_int(IP_VARIANTS[variant]), C.c_int64(len(out)), _p(obs, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ip_terminal(variant, obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 4)
+    out = np.empty(obs.shape[0], np.uint8)
+    lib().emei_oracle_ip_terminal(C.c_int(IP_VARIANTS[variant]), C.c_int64(len(out)), _p(obs, C.c_double), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
+def ip_wrap(theta):
+    th = np.ascontiguousarray(theta, np.float64).reshape(-1)
+    out = np.empty_like(th)
+    lib().emei_oracle_ip_wrap(C.c_int64(len(th)), _p(th, C.c_double), _p(out, C.c_double))
+    return out
