@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the fused env-step hot path on N GPUs of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  Rank 0 prints ONE JSON line.
+
+A bench "step" = one pass of the hot path over one batch of synthetic input: `emei_rollout` of
+`--horizon` (default 1000 = max_episode_steps of CartPoleSwingUp-v0, register_env.py:19-23) env-steps
+for every env of the shard, in one launch, with device-side auto-reset.
+value = env-steps/s over all ranks = n_gpus * envs_per_gpu * horizon * K / time.
+Inputs (state, actions) are resident in HBM before the timed region; outputs land in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (env, envs_per_gpu, freq_rate, dt, horizon, act bytes, obs_dim, act_dim)
+    "cartpole_swingup": dict(env="CartPoleSwingUp", n=65536, freq_rate=1, dt=0.02, horizon=1000,
+                             desc="CartPoleSwingUp-v0, 65 536 parallel envs, freq_ratio=1 (BASELINE configs[1])"),
+    "cartpole_balancing": dict(env="CartPoleBalancing", n=65536, freq_rate=1, dt=0.02, horizon=500,
+                               desc="CartPoleBalancing-v0, 65 536 parallel envs"),
+    "invpend": dict(env="BoundaryInvertedPendulumSwingUp", n=262144, freq_rate=4, dt=0.02, horizon=250,
+                    desc="InvertedPendulum forward-Euler, 262 144 parallel envs, freq_ratio=4 (BASELINE configs[2])"),
+    "cheetah": dict(env="HalfCheetahRunning", n=131072, freq_rate=4, dt=0.002, horizon=100,
+                    desc="HalfCheetah-style body forward-Euler, 131 072 parallel envs (BASELINE configs[3])"),
+}
+
+
+def algorithmic_bytes_per_env_step(obs_dim, act_bytes):
+    """Fused rollout, state in registers: read action, write obs f32 + reward f32 + done u8."""
+    return act_bytes + 4 * obs_dim + 4 + 1
+
+
+def cpu_baseline(env, n, freq_rate, dt, budget_s=12.0):
+    """The CPU oracle ("port": the C restatement of the reference's step arithmetic, pinned
+    bit-exact to the reference by tests/golden) timed on this box's host cores with OpenMP."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    if not env.startswith("CartPole"):
+        return None
+    variant = "swingup" if env == "CartPoleSwingUp" else "balancing"
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    st = O.cartpole_init_state_host(variant, 0, n)
+    acts = np.random.default_rng(1).integers(2, size=(64, n)).astype(np.int32)
+    O.cartpole_step(variant, st, acts[0], freq_rate, dt)  # warm (build + first touch)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        st, _, _ = O.cartpole_step(variant, st, acts[steps % 64], freq_rate, dt)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 1000:
+            break
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of {n} {env} envs with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cartpole_swingup", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if not os.path.exists(os.path.join(ROOT, "emei_amd", "libemei_hip.so")):
+        if rank == 0:
+            ge.build()
+        if dist:
+            dist.barrier()
+
+    from emei_amd.engine import Engine
+    from emei_amd.sharding import ShardedRollout
+
+    w = dict(WORKLOADS[a.workload])
+    N = a.envs_per_gpu or w["n"]
+    T = a.horizon or w["horizon"]
+    env = w["env"]
+    sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
+                        rank=rank, world=world, device=local_rank, seed=0)
+    sr.make_synthetic_inputs()
+
+    for _ in range(a.warmup):
+        sr.run_pass()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sr.run_pass(record=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    kernel_ms = sr.mean_kernel_ms()  # HIP events on the launch stream, this rank
+    total_env_steps = world * N * T * a.steps
+    value = total_env_steps / el
+    bpes = algorithmic_bytes_per_env_step(sr.obs_dim, sr.action_bytes)
+    achieved = bpes * N * T / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a.workload)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if a.precision == "ref" else "f32", "data": "synthetic",
+        "config": {"workload": w["desc"], "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
+                   "real_time_scale": w["dt"], "api": "emei_rollout (one launch per horizon, device auto-reset)",
+                   "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
+                   "obs_allgather": "final obs of each pass over RCCL" if world > 1 else "n/a (1 GPU)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": sr.kernel_name,
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes},
+    }
+    if a.per_step_api and rank == 0:
+        out["per_step_api"] = sr.time_per_step_api()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(env, N, w["freq_rate"], w["dt"])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""ctypes binding of libemei_hip.so (C ABI: include/emei_hip.h).
+
+The HIP library is the product path: there is no CPU or PyTorch fallback.  If the shared object is
+missing or does not export the ABI, importing this module's `lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemei_hip.so")
+
+# enum emei_env_id
+ENV_IDS = {
+    "CartPoleSwingUp": 0,
+    "CartPoleBalancing": 1,
+    "ReboundInvertedPendulumBalancing": 2,
+    "BoundaryInvertedPendulumBalancing": 3,
+    "ReboundInvertedPendulumSwingUp": 4,
+    "BoundaryInvertedPendulumSwingUp": 5,
+    "HalfCheetahRunning": 6,
+}
+PRECISION_REF, PRECISION_F32 = 0, 1
+ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
+FLAG_AUTO_RESET = 1
+DONE_TERMINAL, DONE_TRUNCATED = 1, 2
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
+ABI_VERSION = 1
+
+
+class EmeiConfig(C.Structure):
+    """struct emei_config (include/emei_hip.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("env_id", C.c_int32),
+        ("n_envs", C.c_int64),
+        ("freq_rate", C.c_int32),
+        ("precision", C.c_int32),
+        ("real_time_scale", C.c_double),
+        ("max_episode_steps", C.c_int32),
+        ("device", C.c_int32),
+        ("seed", C.c_uint64),
+        ("env_index_offset", C.c_uint64),
+        ("init_noise", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/emei_hip.h declares
+_vp, _i32, _i64, _u32, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+SYMBOLS = {
+    "emei_create": (C.c_int, [C.POINTER(EmeiConfig), C.POINTER(_vp)]),
+    "emei_destroy": (C.c_int, [_vp]),
+    "emei_last_error": (C.c_char_p, []),
+    "emei_abi_version": (C.c_int, []),
+    "emei_env_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "emei_reset": (C.c_int, [_vp, _u64, _vp]),
+    "emei_set_state": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "emei_get_state": (C.c_int, [_vp, _vp, _vp]),
+    "emei_get_obs": (C.c_int, [_vp, _vp, _vp]),
+    "emei_freeze": (C.c_int, [_vp, _vp]),
+    "emei_unfreeze": (C.c_int, [_vp, _vp]),
+    "emei_step": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
+    "emei_rollout": (C.c_int, [_vp, _i32, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
+    "emei_compact_done": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "emei_reward": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _dbl, _i32, _vp, _vp]),
+    "emei_terminal": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp]),
+    "emei_next_obs": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class EmeiHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libemei_hip.so; fail loudly (no fallback) when it is absent or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EmeiHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C emei_amd/csrc`). emei_amd has no CPU fallback."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if l.emei_abi_version() != ABI_VERSION:
+            raise EmeiHipError(f"libemei_hip.so ABI {l.emei_abi_version()} != binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    """Map ABI status codes onto the exceptions the reference raises at the same places."""
+    if rc == OK:
+        return
+    msg = lib().emei_last_error().decode()
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_STATE:
+        raise AssertionError(msg)  # `assert self.state is not None`, base_control.py:67
+    raise EmeiHipError(msg)

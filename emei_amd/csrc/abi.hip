@@ -1,0 +1,377 @@
+// abi.hip — the extern "C" boundary of libemei_hip.so (declared in include/emei_hip.h).
+// Host code only: argument checks, handle bookkeeping, launch dispatch.  No call in a launch path
+// allocates, frees or synchronises (HIP-graph capturable).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "launch.h"
+#include "cheetah.h"
+
+using namespace emei;
+
+struct emei_env {
+    emei_config cfg;
+    int obs_dim, act_dim, state_dim;
+    size_t real_size;
+    void* state;
+    int32_t* steps;
+    uint32_t* episode;
+    unsigned long long* done_mask;
+    void* frozen_state;
+    int32_t* frozen_steps;
+    uint32_t* frozen_episode;
+    bool has_state, frozen;
+    PendParams pend;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(EMEI_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" EMEI_API const char* emei_last_error(void) { return g_err; }
+extern "C" EMEI_API int emei_abi_version(void) { return EMEI_ABI_VERSION; }
+
+extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, int* state_dim) {
+    int od, ad, sd;
+    switch (env_id) {
+        case EMEI_CARTPOLE_SWINGUP:
+        case EMEI_CARTPOLE_BALANCING: od = 4, ad = 0, sd = 4; break;
+        case EMEI_IP_REBOUND_BALANCING:
+        case EMEI_IP_BOUNDARY_BALANCING:
+        case EMEI_IP_REBOUND_SWINGUP:
+        case EMEI_IP_BOUNDARY_SWINGUP: od = 4, ad = 1, sd = 4; break;
+        case EMEI_HALFCHEETAH_RUNNING: od = 18, ad = 6, sd = 18; break;
+        default: return fail(EMEI_ERR_INVALID, "unknown env_id %d", env_id);
+    }
+    if (obs_dim) *obs_dim = od;
+    if (act_dim) *act_dim = ad;
+    if (state_dim) *state_dim = sd;
+    return EMEI_OK;
+}
+
+static bool is_pend(int env_id) { return env_id >= EMEI_CARTPOLE_SWINGUP && env_id <= EMEI_IP_BOUNDARY_SWINGUP; }
+
+// ---------------------------------------------------------------------------------------------
+// InvertedPendulum model constants from emei/envs/mujoco/assets/inverted_pendulum.xml
+// (gravity :8; slider range :14; cart capsule :15; hinge :17; pole capsule :18; motor :23);
+// capsule mass/inertia are the closed forms MuJoCo's compiler applies for inertiafromgeom.
+static double capsule_mass(double rho, double r, double half) {
+    return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r);
+}
+static double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+
+static PendParams pend_params(int env_id, double dt, double init_noise) {
+    PendParams p;
+    memset(&p, 0, sizeof(p));
+    p.dt = dt;
+    p.dt32 = (float)dt;
+    p.init_sigma = (float)init_noise;
+    const double rho = 1000.0, g = 9.81;
+    double mc = capsule_mass(rho, 0.1, 0.1);
+    double fx = 0.001, fz = 0.6, len = std::sqrt(fx * fx + fz * fz);
+    double mp = capsule_mass(rho, 0.049, len / 2), Icom = capsule_inertia_perp(rho, 0.049, len / 2), r = len / 2;
+    double phi0 = std::atan2(fx, fz);
+    bool swingup = env_id == EMEI_IP_REBOUND_SWINGUP || env_id == EMEI_IP_BOUNDARY_SWINGUP;
+    p.M11 = mc + mp;
+    p.M22 = Icom + mp * r * r;
+    p.mpr = mp * r;
+    p.mgr = mp * g * r;
+    p.gear = 100.0;
+    p.ctrl_lo = -3.0, p.ctrl_hi = 3.0;
+    p.x_lo = -2.0, p.x_hi = 2.0;
+    p.phi_off = phi0 + (swingup ? M_PI : 0.0);  // _update_model: pole body turned by pi about y
+    p.sin_off = std::sin(p.phi_off);
+    p.cos_off = std::cos(p.phi_off);
+    double c0 = std::cos(phi0), M12 = p.mpr * c0;
+    p.invw = p.M22 / (p.M11 * p.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
+    p.tc = 0.02 < 2 * dt ? 2 * dt : 0.02;          // solref timeconst with MuJoCo's refsafe clamp
+    p.dampratio = 1.0, p.dmin = 0.9, p.dmax = 0.95, p.width = 0.001;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
+    if (!cfg || !out) return fail(EMEI_ERR_INVALID, "emei_create: null argument");
+    if (cfg->struct_size != sizeof(emei_config))
+        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu", cfg->struct_size,
+                    sizeof(emei_config));
+    int od, ad, sd;
+    if (emei_env_dims(cfg->env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
+    if (cfg->n_envs <= 0 || cfg->n_envs > (int64_t)1 << 31)
+        return fail(EMEI_ERR_INVALID, "emei_create: n_envs=%lld out of range", (long long)cfg->n_envs);
+    if (cfg->freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_create: freq_rate=%d < 1", cfg->freq_rate);
+    if (!(cfg->real_time_scale > 0)) return fail(EMEI_ERR_INVALID, "emei_create: real_time_scale must be > 0");
+    if (cfg->precision != EMEI_PRECISION_REF && cfg->precision != EMEI_PRECISION_F32)
+        return fail(EMEI_ERR_INVALID, "emei_create: precision=%d", cfg->precision);
+    if (cfg->max_episode_steps < 0) return fail(EMEI_ERR_INVALID, "emei_create: max_episode_steps < 0");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    emei_env* h = new (std::nothrow) emei_env();
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_create: out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->obs_dim = od, h->act_dim = ad, h->state_dim = sd;
+    h->real_size = cfg->precision == EMEI_PRECISION_F32 ? sizeof(float) : sizeof(double);
+    const size_t n = (size_t)cfg->n_envs, n_words = (n + kWave - 1) / kWave;
+    const size_t state_bytes = n * sd * h->real_size;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&h->state, state_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->steps, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->episode, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->done_mask, n_words * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->frozen_state, state_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->frozen_steps, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->frozen_episode, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(h->done_mask, 0, n_words * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->steps, 0, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(h->episode, 0, n * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        emei_destroy(h);
+        return fail(EMEI_ERR_HIP, "emei_create: allocation failed: %s", hipGetErrorString(e));
+    }
+    if (is_pend(cfg->env_id)) h->pend = pend_params(cfg->env_id, cfg->real_time_scale, cfg->init_noise);
+    *out = h;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_destroy(emei_env* h) {
+    if (!h) return EMEI_OK;
+    (void)hipFree(h->state);
+    (void)hipFree(h->steps);
+    (void)hipFree(h->episode);
+    (void)hipFree(h->done_mask);
+    (void)hipFree(h->frozen_state);
+    (void)hipFree(h->frozen_steps);
+    (void)hipFree(h->frozen_episode);
+    delete h;
+    return EMEI_OK;
+}
+
+static PendLaunch pend_base(emei_env* h, void* stream) {
+    PendLaunch L;
+    L.env_id = h->cfg.env_id;
+    L.precision = h->cfg.precision;
+    L.state = h->state;
+    L.steps = h->steps;
+    L.episode = h->episode;
+    L.done_mask = h->done_mask;
+    L.n = h->cfg.n_envs;
+    L.freq_rate = h->cfg.freq_rate;
+    L.max_episode_steps = h->cfg.max_episode_steps;
+    L.seed = h->cfg.seed;
+    L.env_offset = h->cfg.env_index_offset;
+    L.p = h->pend;
+    L.stream = (hipStream_t)stream;
+    return L;
+}
+
+extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_reset: null handle");
+    h->cfg.seed = seed;
+    int rc;
+    if (is_pend(h->cfg.env_id)) {
+        PendLaunch L = pend_base(h, stream);
+        L.op = PEND_OP_RESET;
+        rc = pend_launch(L);
+    } else {
+        rc = cheetah_reset(h->state, h->steps, h->episode, h->cfg.n_envs, h->cfg.precision, seed,
+                           h->cfg.env_index_offset, h->cfg.init_noise, (hipStream_t)stream);
+    }
+    if (rc != EMEI_OK) return fail(rc, "emei_reset: launch failed");
+    h->has_state = true;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_set_state(emei_env* h, const double* state_aos, int reset_counters, void* stream) {
+    if (!h || !state_aos) return fail(EMEI_ERR_INVALID, "emei_set_state: null argument");
+    int rc = launch_state_unpack(state_aos, h->state, h->cfg.precision, h->cfg.n_envs, h->state_dim, (hipStream_t)stream);
+    if (rc != EMEI_OK) return fail(rc, "emei_set_state: launch failed");
+    if (reset_counters) {
+        HIP_TRY(hipMemsetAsync(h->steps, 0, (size_t)h->cfg.n_envs * sizeof(int32_t), (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(h->episode, 0, (size_t)h->cfg.n_envs * sizeof(uint32_t), (hipStream_t)stream));
+    }
+    h->has_state = true;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_get_state(emei_env* h, double* state_aos, void* stream) {
+    if (!h || !state_aos) return fail(EMEI_ERR_INVALID, "emei_get_state: null argument");
+    if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_get_state: call reset before using the state");
+    int rc = launch_state_pack(h->state, state_aos, h->cfg.precision, h->cfg.n_envs, h->state_dim, (hipStream_t)stream);
+    return rc == EMEI_OK ? rc : fail(rc, "emei_get_state: launch failed");
+}
+
+extern "C" EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream) {
+    if (!h || !obs_aos) return fail(EMEI_ERR_INVALID, "emei_get_obs: null argument");
+    if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_get_obs: call reset before using the state");
+    if (is_pend(h->cfg.env_id)) {
+        PendLaunch L = pend_base(h, stream);
+        L.op = PEND_OP_GET_OBS;
+        L.obs_f64 = obs_aos;
+        int rc = pend_launch(L);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_get_obs: launch failed");
+    }
+    // HalfCheetah: obs = concat(qpos, qvel) = the state itself (mujoco_env.py:153-155)
+    return emei_get_state(h, obs_aos, stream);
+}
+
+extern "C" EMEI_API int emei_freeze(emei_env* h, void* stream) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_freeze: null handle");
+    if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_freeze: no state to freeze (call reset first)");
+    const size_t n = (size_t)h->cfg.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->frozen_state, h->state, n * h->state_dim * h->real_size, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->frozen_steps, h->steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->frozen_episode, h->episode, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    h->frozen = true;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_unfreeze(emei_env* h, void* stream) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_unfreeze: null handle");
+    if (!h->frozen) return fail(EMEI_ERR_STATE, "emei_unfreeze: env has not been frozen");
+    const size_t n = (size_t)h->cfg.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->state, h->frozen_state, n * h->state_dim * h->real_size, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->steps, h->frozen_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->episode, h->frozen_episode, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    h->frozen = false;
+    return EMEI_OK;
+}
+
+static int check_action_dtype(const emei_env* h, int action_dtype) {
+    if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype %d", action_dtype);
+    if (h->cfg.env_id == EMEI_HALFCHEETAH_RUNNING && action_dtype != EMEI_ACT_F32)
+        return fail(EMEI_ERR_INVALID, "HalfCheetah actions must be float32 [n,6]");
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* actions, int action_dtype, float* obs_out,
+                            float* reward_out, uint8_t* done_out, uint32_t flags, void* stream) {
+    if (!h || !actions) return fail(EMEI_ERR_INVALID, "emei_rollout: null argument");
+    if (n_steps < 1) return fail(EMEI_ERR_INVALID, "emei_rollout: n_steps=%d < 1", n_steps);
+    if (!h->has_state) return fail(EMEI_ERR_STATE, "Call reset before using step method.");  // base_control.py:67
+    if (flags & ~EMEI_FLAG_AUTO_RESET) return fail(EMEI_ERR_INVALID, "emei_rollout: unknown flags 0x%x", flags);
+    if (check_action_dtype(h, action_dtype) != EMEI_OK) return EMEI_ERR_INVALID;
+    int rc;
+    if (is_pend(h->cfg.env_id)) {
+        PendLaunch L = pend_base(h, stream);
+        L.op = PEND_OP_ROLLOUT;
+        L.actions = actions;
+        L.action_dtype = action_dtype;
+        L.obs_out = obs_out;
+        L.reward_out = reward_out;
+        L.done_out = done_out;
+        L.n_steps = n_steps;
+        L.flags = flags;
+        rc = pend_launch(L);
+    } else {
+        rc = cheetah_rollout(h->state, h->steps, h->episode, h->done_mask, h->cfg.n_envs, h->cfg.precision, n_steps,
+                             h->cfg.freq_rate, h->cfg.real_time_scale, h->cfg.max_episode_steps, h->cfg.seed,
+                             h->cfg.env_index_offset, h->cfg.init_noise, (const float*)actions, obs_out, reward_out,
+                             done_out, flags, (hipStream_t)stream);
+    }
+    return rc == EMEI_OK ? rc : fail(rc, "emei_rollout: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+}
+
+extern "C" EMEI_API int emei_step(emei_env* h, const void* actions, int action_dtype, float* obs_out, float* reward_out,
+                         uint8_t* done_out, uint32_t flags, void* stream) {
+    return emei_rollout(h, 1, actions, action_dtype, obs_out, reward_out, done_out, flags, stream);
+}
+
+extern "C" EMEI_API int emei_compact_done(emei_env* h, int32_t* idx_out, int32_t* count_out, void* stream) {
+    if (!h || !idx_out || !count_out) return fail(EMEI_ERR_INVALID, "emei_compact_done: null argument");
+    int rc = launch_compact_done(h->done_mask, h->cfg.n_envs, idx_out, count_out, (hipStream_t)stream);
+    return rc == EMEI_OK ? rc : fail(rc, "emei_compact_done: launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                           double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {
+    if (n <= 0 || !obs || !reward_out) return fail(EMEI_ERR_INVALID, "emei_reward: bad argument");
+    if (is_pend(env_id)) {
+        PendLaunch L;
+        L.op = PEND_OP_REWARD_TERMINAL;
+        L.env_id = env_id;
+        L.precision = EMEI_PRECISION_F32;
+        L.obs_in = obs;
+        L.reward_out = reward_out;
+        L.n = n;
+        L.p = pend_params(env_id, real_time_scale > 0 ? real_time_scale : 0.02, 0.0);
+        L.stream = (hipStream_t)stream;
+        int rc = pend_launch(L);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
+    }
+    if (env_id == EMEI_HALFCHEETAH_RUNNING) {
+        if (!pre_obs || !action) return fail(EMEI_ERR_INVALID, "emei_reward: HalfCheetah needs pre_obs and action");
+        if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_reward: bad dt/freq_rate");
+        int rc = cheetah_reward(n, obs, pre_obs, action, real_time_scale * freq_rate, reward_out, (hipStream_t)stream);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
+    }
+    return fail(EMEI_ERR_INVALID, "emei_reward: unknown env_id %d", env_id);
+}
+
+extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream) {
+    if (n <= 0 || !obs || !terminal_out) return fail(EMEI_ERR_INVALID, "emei_terminal: bad argument");
+    if (is_pend(env_id)) {
+        PendLaunch L;
+        L.op = PEND_OP_REWARD_TERMINAL;
+        L.env_id = env_id;
+        L.precision = EMEI_PRECISION_F32;
+        L.obs_in = obs;
+        L.done_out = terminal_out;
+        L.n = n;
+        L.p = pend_params(env_id, 0.02, 0.0);
+        L.stream = (hipStream_t)stream;
+        int rc = pend_launch(L);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
+    }
+    if (env_id == EMEI_HALFCHEETAH_RUNNING) {
+        int rc = cheetah_terminal(n, obs, terminal_out, (hipStream_t)stream);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
+    }
+    return fail(EMEI_ERR_INVALID, "emei_terminal: unknown env_id %d", env_id);
+}
+
+extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                             double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
+                             void* stream) {
+    if (n <= 0 || !obs || !actions || !next_obs_out) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad argument");
+    if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad dt/freq_rate");
+    if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype");
+    if (!is_pend(env_id))
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_next_obs: not implemented for env_id %d", env_id);  // core.py:190-193
+    PendLaunch L;
+    L.op = PEND_OP_NEXT_OBS;
+    L.env_id = env_id;
+    L.precision = precision;
+    L.obs_in = obs;
+    L.actions = actions;
+    L.action_dtype = action_dtype;
+    L.obs_out = next_obs_out;
+    L.n = n;
+    L.freq_rate = freq_rate;
+    L.p = pend_params(env_id, real_time_scale, 0.0);
+    L.stream = (hipStream_t)stream;
+    int rc = pend_launch(L);
+    return rc == EMEI_OK ? rc : fail(rc, "emei_next_obs: launch failed");
+}

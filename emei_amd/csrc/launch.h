@@ -1,0 +1,41 @@
+// launch.h — host-side launch descriptors shared between the ABI layer and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pendulum_envs.h"
+
+namespace emei {
+
+enum PendOp { PEND_OP_ROLLOUT = 0, PEND_OP_RESET, PEND_OP_GET_OBS, PEND_OP_REWARD_TERMINAL, PEND_OP_NEXT_OBS };
+
+struct PendLaunch {
+    int op = PEND_OP_ROLLOUT;
+    int env_id = 0, precision = 0;
+    void* state = nullptr;
+    int32_t* steps = nullptr;
+    uint32_t* episode = nullptr;
+    unsigned long long* done_mask = nullptr;
+    const void* actions = nullptr;
+    const float* obs_in = nullptr;
+    float* obs_out = nullptr;
+    double* obs_f64 = nullptr;
+    float* reward_out = nullptr;
+    uint8_t* done_out = nullptr;
+    int64_t n = 0;
+    int32_t n_steps = 1, freq_rate = 1, action_dtype = 0, max_episode_steps = 0;
+    uint32_t flags = 0;
+    uint64_t seed = 0, env_offset = 0;
+    PendParams p;
+    hipStream_t stream = nullptr;
+};
+
+// pendulum_kernels.hip
+int pend_launch(const PendLaunch& L);
+
+// util_kernels.hip
+int launch_state_unpack(const double* aos, void* soa, int precision, int64_t n, int dim, hipStream_t s);
+int launch_state_pack(const void* soa, double* aos, int precision, int64_t n, int dim, hipStream_t s);
+int launch_compact_done(const unsigned long long* masks, int64_t n, int32_t* idx_out, int32_t* count_out, hipStream_t s);
+
+}  // namespace emei

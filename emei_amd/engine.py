@@ -1,0 +1,160 @@
+"""Batched env engine: a thin, torch-tensor-facing wrapper of the C ABI handle.
+
+PyTorch is plumbing here (device memory + streams); every computation happens in libemei_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_ACT_DTYPES = {torch.uint8: L.ACT_U8, torch.int32: L.ACT_I32, torch.int64: L.ACT_I64, torch.float32: L.ACT_F32}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def env_dims(env_name):
+    od, ad, sd = C.c_int(), C.c_int(), C.c_int()
+    L.check(L.lib().emei_env_dims(L.ENV_IDS[env_name], C.byref(od), C.byref(ad), C.byref(sd)))
+    return od.value, ad.value, sd.value
+
+
+class Engine:
+    """N independent env instances of one kind on one GPU (this rank's shard)."""
+
+    def __init__(self, env_name, n_envs, freq_rate=1, real_time_scale=0.02, precision="ref", max_episode_steps=0,
+                 device=None, seed=0, env_index_offset=0, init_noise=0.0):
+        if env_name not in L.ENV_IDS:
+            raise ValueError(f"unknown env {env_name!r}; known: {sorted(L.ENV_IDS)}")
+        if not torch.cuda.is_available():
+            raise L.EmeiHipError("emei_amd needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.env_name, self.n_envs = env_name, int(n_envs)
+        self.freq_rate, self.real_time_scale = int(freq_rate), float(real_time_scale)
+        self.precision = {"ref": L.PRECISION_REF, "f32": L.PRECISION_F32}[precision]
+        self.obs_dim, self.act_dim, self.state_dim = env_dims(env_name)
+        cfg = L.EmeiConfig(C.sizeof(L.EmeiConfig), L.ENV_IDS[env_name], self.n_envs, self.freq_rate, self.precision,
+                           self.real_time_scale, int(max_episode_steps), self.device.index, int(seed),
+                           int(env_index_offset), float(init_noise))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().emei_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().emei_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------------
+    def reset(self, seed=0):
+        L.check(L.lib().emei_reset(self._h, int(seed) & (2**64 - 1), _stream()))
+
+    def set_state(self, state, reset_counters=True):
+        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).contiguous()
+        if tuple(st.shape) != (self.n_envs, self.state_dim):
+            raise ValueError(f"state shape {tuple(st.shape)} != {(self.n_envs, self.state_dim)}")
+        L.check(L.lib().emei_set_state(self._h, _ptr(st), int(bool(reset_counters)), _stream()))
+        torch.cuda.current_stream().synchronize()  # `st` may be a temporary
+
+    def get_state(self):
+        out = torch.empty((self.n_envs, self.state_dim), dtype=torch.float64, device=self.device)
+        L.check(L.lib().emei_get_state(self._h, _ptr(out), _stream()))
+        return out
+
+    def get_obs(self):
+        out = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float64, device=self.device)
+        L.check(L.lib().emei_get_obs(self._h, _ptr(out), _stream()))
+        return out
+
+    def freeze(self):
+        L.check(L.lib().emei_freeze(self._h, _stream()))
+
+    def unfreeze(self):
+        L.check(L.lib().emei_unfreeze(self._h, _stream()))
+
+    # -- hot path ------------------------------------------------------------------------------
+    def _check_actions(self, actions, lead):
+        if not isinstance(actions, torch.Tensor) or actions.device != self.device:
+            raise ValueError("actions must be a tensor on the engine's device")
+        if actions.dtype not in _ACT_DTYPES:
+            raise ValueError(f"unsupported action dtype {actions.dtype}")
+        want = lead + ((self.n_envs,) if self.act_dim <= 1 else (self.n_envs, self.act_dim))
+        shape = tuple(actions.shape)
+        if shape != want and not (self.act_dim == 1 and shape == lead + (self.n_envs, 1)):
+            raise ValueError(f"actions shape {shape} != {want}")
+        if not actions.is_contiguous():
+            raise ValueError("actions must be contiguous")
+        return _ACT_DTYPES[actions.dtype]
+
+    def step(self, actions, auto_reset=False, out=None):
+        """-> obs [N,obs_dim] f32, reward [N] f32, done [N] u8 (bit0 terminal, bit1 truncated)."""
+        dt = self._check_actions(actions, ())
+        obs, rew, done = out if out is not None else self.alloc_outputs(None)
+        L.check(L.lib().emei_step(self._h, _ptr(actions), dt, _ptr(obs), _ptr(rew), _ptr(done),
+                                  L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
+        return obs, rew, done
+
+    def rollout(self, actions, auto_reset=False, out=None):
+        """actions [T,N(,act_dim)] -> obs [T,N,obs_dim] f32, reward [T,N] f32, done [T,N] u8; one launch."""
+        T = int(actions.shape[0])
+        dt = self._check_actions(actions, (T,))
+        obs, rew, done = out if out is not None else self.alloc_outputs(T)
+        L.check(L.lib().emei_rollout(self._h, T, _ptr(actions), dt, _ptr(obs), _ptr(rew), _ptr(done),
+                                     L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
+        return obs, rew, done
+
+    def alloc_outputs(self, n_steps=None):
+        lead = () if n_steps is None else (int(n_steps),)
+        return (torch.empty(lead + (self.n_envs, self.obs_dim), dtype=torch.float32, device=self.device),
+                torch.empty(lead + (self.n_envs,), dtype=torch.float32, device=self.device),
+                torch.empty(lead + (self.n_envs,), dtype=torch.uint8, device=self.device))
+
+    def compact_done(self):
+        """Sorted indices of the envs that were done at the last step (int32 tensor)."""
+        idx = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        L.check(L.lib().emei_compact_done(self._h, _ptr(idx), _ptr(cnt), _stream()))
+        return idx[: int(cnt.item())]
+
+
+# -- stateless batched functions -----------------------------------------------------------------
+def _f32c(t, device):
+    return None if t is None else torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+
+
+def batch_reward(env_name, obs, pre_obs=None, action=None, real_time_scale=0.02, freq_rate=1):
+    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    pre_obs, action = _f32c(pre_obs, obs.device), _f32c(action, obs.device)
+    out = torch.empty(obs.shape[0], dtype=torch.float32, device=obs.device)
+    L.check(L.lib().emei_reward(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(pre_obs), _ptr(action),
+                                float(real_time_scale), int(freq_rate), _ptr(out), _stream()))
+    return out
+
+
+def batch_terminal(env_name, obs):
+    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    out = torch.empty(obs.shape[0], dtype=torch.uint8, device=obs.device)
+    L.check(L.lib().emei_terminal(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(out), _stream()))
+    return out.bool()
+
+
+def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref"):
+    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    actions = actions.to(obs.device).contiguous()
+    out = torch.empty_like(obs)
+    L.check(L.lib().emei_next_obs(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(actions), _ACT_DTYPES[actions.dtype],
+                                  float(real_time_scale), int(freq_rate), {"ref": 0, "f32": 1}[precision], _ptr(out),
+                                  _stream()))
+    return out

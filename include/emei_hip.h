@@ -1,0 +1,155 @@
+/*
+ * emei_hip.h — C ABI of libemei_hip.so, the MI355X (gfx950) env-step engine.
+ *
+ * The reference (polixir/emei) has no FFI boundary: its "operator API" for this path is the Python
+ * class surface.  Each entry point below names the reference interface it replaces (file:line under
+ * /root/reference).  All pointers are caller-owned DEVICE pointers (e.g. torch.Tensor.data_ptr()),
+ * contiguous, never retained past the call.  The library never allocates outputs, never
+ * synchronises the stream and never throws across the boundary.  `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  One handle <-> one device; a handle is not thread-safe,
+ * distinct handles are.
+ *
+ * Return value: 0 = ok, negative = error (EMEI_ERR_*); emei_last_error() gives a thread-local text.
+ */
+#ifndef EMEI_HIP_H
+#define EMEI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMEI_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define EMEI_API __attribute__((visibility("default")))
+#else
+#define EMEI_API
+#endif
+
+/* Environments (reference classes). */
+enum emei_env_id {
+    EMEI_CARTPOLE_SWINGUP = 0,      /* emei/envs/classic_control/cartpole.py:135-156 */
+    EMEI_CARTPOLE_BALANCING = 1,    /* emei/envs/classic_control/cartpole.py:115-132 */
+    EMEI_IP_REBOUND_BALANCING = 2,  /* emei/envs/mujoco/inverted_pendulum.py:52-79   */
+    EMEI_IP_BOUNDARY_BALANCING = 3, /* emei/envs/mujoco/inverted_pendulum.py:82-111  */
+    EMEI_IP_REBOUND_SWINGUP = 4,    /* emei/envs/mujoco/inverted_pendulum.py:114-146 */
+    EMEI_IP_BOUNDARY_SWINGUP = 5,   /* emei/envs/mujoco/inverted_pendulum.py:149-183 */
+    EMEI_HALFCHEETAH_RUNNING = 6,   /* emei/envs/mujoco/half_cheetah.py:16-67        */
+    EMEI_NUM_ENVS_IDS = 7
+};
+
+/* Arithmetic the kernels compute in.
+ * REF  : float64 state and derivative, mirroring the reference's own precision (classic control:
+ *        float64 accumulator += float32(derivative)*float32(dt), base_control.py:162-164 and
+ *        cartpole.py:60; MuJoCo bodies: float64 throughout).  State arrays in HBM are float64.
+ * F32  : float32 state and arithmetic (fast mode; not bit-faithful on long chaotic trajectories). */
+enum emei_precision { EMEI_PRECISION_REF = 0, EMEI_PRECISION_F32 = 1 };
+
+/* dtype of the `actions` argument of emei_step / emei_rollout. */
+enum emei_action_dtype { EMEI_ACT_U8 = 0, EMEI_ACT_I32 = 1, EMEI_ACT_I64 = 2, EMEI_ACT_F32 = 3 };
+
+/* flags of emei_step / emei_rollout */
+#define EMEI_FLAG_AUTO_RESET 1u /* re-initialise an env on the device when done (terminal|truncated) */
+
+/* done byte written by emei_step / emei_rollout */
+#define EMEI_DONE_TERMINAL 1u  /* reference `terminal` (get_batch_terminal) */
+#define EMEI_DONE_TRUNCATED 2u /* gym TimeLimit `truncated` (register_env.py max_episode_steps) */
+
+/* error codes */
+#define EMEI_OK 0
+#define EMEI_ERR_INVALID -1     /* bad argument (the reference asserts / raises ValueError) */
+#define EMEI_ERR_HIP -2         /* a HIP runtime call failed */
+#define EMEI_ERR_UNSUPPORTED -3 /* the reference raises NotImplementedError here */
+#define EMEI_ERR_STATE -4       /* call order: e.g. step before reset (base_control.py:67) */
+
+typedef struct emei_env emei_env; /* opaque */
+
+typedef struct emei_config {
+    uint32_t struct_size;       /* = sizeof(emei_config), ABI evolution */
+    int32_t env_id;             /* enum emei_env_id */
+    int64_t n_envs;             /* env instances owned by this handle (this rank's shard) */
+    int32_t freq_rate;          /* substeps per step (base_control.py:17, mujoco_env.py:42) */
+    int32_t precision;          /* enum emei_precision */
+    double real_time_scale;     /* dt of ONE substep; NOT divided by freq_rate (base_control.py:73) */
+    int32_t max_episode_steps;  /* TimeLimit (register_env.py:14-66); 0 = never truncate */
+    int32_t device;             /* HIP device ordinal */
+    uint64_t seed;              /* key of the device-side reset generator */
+    uint64_t env_index_offset;  /* global index of env 0 of this shard (results independent of sharding) */
+    double init_noise;          /* sigma of the Gaussian init noise of the MuJoCo bodies (mujoco_env.py:31) */
+} emei_config;
+
+/* -- lifecycle ------------------------------------------------------------------------------- */
+/* Replaces Env.__init__(freq_rate, real_time_scale, integrator, ...) (base_control.py:14-30;
+ * mujoco_env.py:24-62).  Allocates the state SoA on cfg->device. */
+EMEI_API int emei_create(const emei_config* cfg, emei_env** out);
+EMEI_API int emei_destroy(emei_env* h);
+EMEI_API const char* emei_last_error(void);
+EMEI_API int emei_abi_version(void);
+
+/* Static facts about an env id: obs_dim, act_dim (0 = discrete scalar action), state_dim. */
+EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, int* state_dim);
+
+/* -- reset / state --------------------------------------------------------------------------- */
+/* Env.reset(seed=) on the device (base_control.py:38-47; mujoco_env.py:130-140): every env gets a
+ * fresh initial state from the counter-based generator keyed by `seed`; step counters and episode
+ * counters are zeroed.  (The reference's host PCG64 / MT19937 streams are reproduced on the host and
+ * uploaded with emei_set_state when bit parity of the initial state is wanted.) */
+EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream);
+
+/* Upload / download the internal state as a row-major [n_envs, state_dim] float64 array
+ * (`self.state` of base_control.py:28,46,74; (qpos,qvel) of mujoco_env.py:116,132).
+ * emei_set_state zeroes the step counters when reset_counters != 0. */
+EMEI_API int emei_set_state(emei_env* h, const double* state_aos, int reset_counters, void* stream);
+EMEI_API int emei_get_state(emei_env* h, double* state_aos, void* stream);
+/* current observation as float64 [n_envs, obs_dim] (current_obs, mujoco_env.py:153-155;
+ * inverted_pendulum.py:45-49) */
+EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream);
+
+/* Freezable.freeze / unfreeze (base_control.py:32-36; mujoco_env.py:114-120): device-to-device
+ * snapshot / restore of the state SoA and counters. */
+EMEI_API int emei_freeze(emei_env* h, void* stream);
+EMEI_API int emei_unfreeze(emei_env* h, void* stream);
+
+/* -- the hot path ---------------------------------------------------------------------------- */
+/* Env.step(action) for all n_envs instances (base_control.py:61-83; mujoco_env.py:157-167):
+ *   actions   [n_envs] (discrete) or [n_envs, act_dim] (continuous), dtype per action_dtype
+ *   obs_out   [n_envs, obs_dim] float32  next observation (before any auto-reset)
+ *   reward_out[n_envs] float32
+ *   done_out  [n_envs] uint8   EMEI_DONE_* bits
+ * Any output pointer may be NULL to skip that output. */
+EMEI_API int emei_step(emei_env* h, const void* actions, int action_dtype, float* obs_out, float* reward_out,
+              uint8_t* done_out, uint32_t flags, void* stream);
+
+/* n_steps fused steps in ONE launch, state kept in registers (the caller loops of zoo/util.py:54-73
+ * and emei/util.py:14-36 collapsed): actions [n_steps, n_envs(, act_dim)], obs_out
+ * [n_steps, n_envs, obs_dim], reward_out [n_steps, n_envs], done_out [n_steps, n_envs].
+ * Results are identical to n_steps calls of emei_step. */
+EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* actions, int action_dtype, float* obs_out,
+                 float* reward_out, uint8_t* done_out, uint32_t flags, void* stream);
+
+/* Sorted indices of the envs whose last step reported done (wavefront-ballot compaction of the done
+ * masks the step kernels leave behind): idx_out [n_envs] int32 (first *count_out entries valid),
+ * count_out [1] int32. */
+EMEI_API int emei_compact_done(emei_env* h, int32_t* idx_out, int32_t* count_out, void* stream);
+
+/* -- stateless batched reward / terminal (model-based-RL callers) ---------------------------- */
+/* EmeiEnv.get_batch_reward / get_batch_terminal (core.py:182-188; cartpole.py:124-129,145-151;
+ * inverted_pendulum.py:73-183; half_cheetah.py:59-67): obs, pre_obs [n, obs_dim] float32,
+ * action [n, act_dim] float32 (may be NULL where the env ignores it), out [n]. */
+EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                double real_time_scale, int32_t freq_rate, float* reward_out, void* stream);
+EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream);
+
+/* EmeiEnv.get_batch_next_obs (core.py:190-193; abstract in the reference, no env implements it):
+ * one step from caller-supplied float32 observations without touching any handle state.
+ * obs [n, obs_dim], action as in emei_step, next_obs_out [n, obs_dim]. */
+EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                  double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMEI_HIP_H */

@@ -186,10 +186,7 @@ static inline float u01(uint32_t r) { return (float)(r >> 8) * 0x1.0p-24f; } /* 
 EXPORT void emei_oracle_cartpole_init_f32(int variant, uint64_t seed, uint64_t env, uint32_t episode, float s[4]) {
     uint32_t r[4];
     emei_oracle_philox(seed, env, episode, 0, r);
-    for (int i = 0; i < 4; ++i) {
-        volatile float sc = 0.1f * u01(r[i]);
-        s[i] = -0.05f + sc;
-    }
+    for (int i = 0; i < 4; ++i) s[i] = fmaf(0.1f, u01(r[i]), -0.05f); /* single rounding */
     if (variant == 0) s[2] += (float)M_PI;
 }
 

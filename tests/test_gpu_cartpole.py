@@ -1,0 +1,106 @@
+"""GPU parity of the CartPole kernels (through the C ABI) against the golden vectors generated from
+the reference and against the CPU oracle.  Tolerance (BASELINE.json north_star): 1e-5 relative on
+float32 trajectories (floor: |ref| < 1 is compared absolutely), terminal masks bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+RTOL = 1e-5
+ENV = {"swingup": "CartPoleSwingUp", "balancing": "CartPoleBalancing"}
+
+
+def _engine(*a, **k):
+    from emei_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr,dt", [(1, 0.02), (4, 0.02), (2, 0.01)])
+@pytest.mark.parametrize("precision", ["ref", "f32"])
+@pytest.mark.parametrize("adtype", ["uint8", "int64"])
+def test_onestep_vs_golden(cartpole_golden, name, fr, dt, precision, adtype):
+    g = cartpole_golden
+    s0, act = g[f"onestep_{name}_state"], g[f"onestep_{name}_action"]
+    tag = f"onestep_{name}_fr{fr}_dt{dt}"
+    ok = ~g[tag + "_raised"]
+    eng = _engine(ENV[name], len(s0), freq_rate=fr, real_time_scale=dt, precision=precision)
+    eng.set_state(s0)
+    a = torch.as_tensor(act, device=eng.device).to(getattr(torch, adtype))
+    obs, rew, done = eng.step(a)
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    nxt, gr, gt = g[tag + "_next"], g[tag + "_reward"], g[tag + "_terminal"]
+    assert rel_err(obs[ok], nxt[ok]) <= RTOL
+    assert rel_err(rew[ok], gr[ok]) <= RTOL
+    # masks: bit-exact wherever the float32/float64 observation is not within tolerance of a threshold
+    thr = 5.0 if name == "swingup" else 2.4
+    margin = np.abs(np.abs(nxt[:, 0]) - thr) < 1e-4
+    if name == "balancing":
+        margin |= np.abs(np.abs(nxt[:, 2]) - 12 * 2 * np.pi / 360) < 1e-5
+    chk = ok & (~margin if precision == "f32" else np.ones_like(ok))
+    assert np.array_equal(done[chk] & 1, gt[chk].astype(np.uint8))
+    assert not (done & 2).any()  # no TimeLimit configured -> never truncated (base_control.py:80)
+    if precision == "ref":
+        st = eng.get_state().cpu().numpy()
+        assert rel_err(st[ok], nxt[ok], floor=1e-30) <= 1e-9  # float64 state: ~bitwise
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr", [1, 4])
+def test_trajectory_ref_precision(cartpole_golden, name, fr):
+    """All 1000 open-loop steps (beyond the first terminal, like the reference which never resets)."""
+    g = cartpole_golden
+    tags = [f"traj_{name}_fr{fr}_seed{s}" for s in range(4)]
+    s0 = np.stack([g[t + "_states"][0] for t in tags])
+    acts = np.stack([g[t + "_actions"] for t in tags], axis=1)  # [T,4]
+    eng = _engine(ENV[name], 4, freq_rate=fr, real_time_scale=0.02, precision="ref")
+    eng.set_state(s0)
+    obs, rew, done = eng.rollout(torch.as_tensor(acts, device=eng.device).to(torch.uint8))
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for k, t in enumerate(tags):
+        assert rel_err(obs[:, k], g[t + "_states"][1:]) <= RTOL, t
+        assert rel_err(rew[:, k], g[t + "_reward"]) <= RTOL, t
+        assert np.array_equal(done[:, k] & 1, g[t + "_terminal"].astype(np.uint8)), t
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+def test_trajectory_f32_until_first_terminal(cartpole_golden, name):
+    """float32 fast mode: chaotic divergence is allowed after the episode ends; before that 1e-4."""
+    g = cartpole_golden
+    for fr in (1, 4):
+        for s in range(4):
+            t = f"traj_{name}_fr{fr}_seed{s}"
+            term = g[t + "_terminal"]
+            first = int(np.argmax(term)) + 1 if term.any() else 200
+            first = min(first, 200)
+            eng = _engine(ENV[name], 1, freq_rate=fr, precision="f32")
+            eng.set_state(g[t + "_states"][:1])
+            a = torch.as_tensor(g[t + "_actions"][:first, None], device=eng.device).to(torch.int32)
+            obs, rew, done = eng.rollout(a)
+            assert rel_err(obs.cpu().numpy()[:, 0], g[t + "_states"][1 : first + 1]) <= 1e-4, t
+
+
+@pytest.mark.parametrize("precision", ["ref", "f32"])
+def test_rollout_equals_repeated_step(precision):
+    N, T = 1000, 37  # ragged: not a multiple of the wave or block size
+    eng_a = _engine("CartPoleSwingUp", N, freq_rate=2, precision=precision, max_episode_steps=20, seed=5)
+    eng_b = _engine("CartPoleSwingUp", N, freq_rate=2, precision=precision, max_episode_steps=20, seed=5)
+    eng_a.reset(5)
+    eng_b.reset(5)
+    acts = torch.randint(0, 2, (T, N), device=eng_a.device, dtype=torch.uint8)
+    obs, rew, done = eng_a.rollout(acts, auto_reset=True)
+    for t in range(T):
+        o, r, d = eng_b.step(acts[t], auto_reset=True)
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t])
+    assert torch.equal(eng_a.get_state(), eng_b.get_state())
+    assert (done & 2).any()  # truncation happened (max_episode_steps=20 < T)
+
+
+def test_step_before_reset_asserts():
+    eng = _engine("CartPoleSwingUp", 8)
+    with pytest.raises(AssertionError, match="Call reset before using step method"):
+        eng.step(torch.zeros(8, dtype=torch.uint8, device=eng.device))
