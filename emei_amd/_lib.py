@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemei_hip.so")
+# EMEI_HIP_LIB lets a developer A/B two builds of the same ABI inside one process launch; the default
+# is the in-tree library next to this file.
+LIB_PATH = os.environ.get("EMEI_HIP_LIB") or os.path.join(_HERE, "libemei_hip.so")
 
 # enum emei_env_id
 ENV_IDS = {
@@ -78,6 +80,10 @@ def lib():
     """Load libemei_hip.so; fail loudly (no fallback) when it is absent or stale."""
     global _lib
     if _lib is None:
+        # torch must be imported first: its bundled HIP runtime and /opt/rocm's share one SONAME, and
+        # whichever loads first serves both; loading ours before torch leaves torch without a device.
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise EmeiHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -260,8 +260,12 @@ extern "C" EMEI_API int emei_unfreeze(emei_env* h, void* stream) {
 
 static int check_action_dtype(const emei_env* h, int action_dtype) {
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype %d", action_dtype);
-    if (h->cfg.env_id == EMEI_HALFCHEETAH_RUNNING && action_dtype != EMEI_ACT_F32)
-        return fail(EMEI_ERR_INVALID, "HalfCheetah actions must be float32 [n,6]");
+    int od, ad, sd;
+    emei_env_dims(h->cfg.env_id, &od, &ad, &sd);
+    if (ad > 0 && action_dtype != EMEI_ACT_F32)
+        return fail(EMEI_ERR_INVALID, "continuous-action envs take float32 actions [n,%d]", ad);
+    if (ad == 0 && action_dtype == EMEI_ACT_F32)
+        return fail(EMEI_ERR_INVALID, "discrete-action envs take uint8/int32/int64 actions [n]");
     return EMEI_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/emei_hip.h"
+#include "emei_math.h"
 
 namespace emei {
 
@@ -11,20 +12,44 @@ constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------------------------
-// trigonometry in the precision of the env
-__device__ __forceinline__ void sincos_r(double x, double& s, double& c) { ::sincos(x, &s, &c); }
-__device__ __forceinline__ void sincos_r(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-
-// Python / NumPy floored modulo (np.remainder): sign follows the divisor.
-__device__ __forceinline__ double pymod(double a, double p) {
-    double m = ::fmod(a, p);
-    if (m != 0.0 && ((m < 0.0) != (p < 0.0))) m += p;
-    return m;
+// trigonometry in the precision of the env.  Fast path: emei_math.h (straight-line, ~35 instructions);
+// the device library's Payne-Hanek sincos only repairs the (practically unreachable) |x| > 1e6 case,
+// AFTER the straight-line code, so that the hot basic block is not split.
+__device__ __forceinline__ void sincos_fast_r(double x, double& s, double& c) { fast_sincos(x, s, c); }
+__device__ __forceinline__ void sincos_fast_r(float x, float& s, float& c) { fast_sincosf(x, s, c); }
+// repair of a fast result for out-of-range arguments; call it at the END of a straight-line block
+__device__ __forceinline__ void sincos_repair_r(double x, double& s, double& c) {
+    if (__builtin_expect(fabs(x) > kFastTrigLimitF64, 0)) ::sincos(x, &s, &c);
 }
-__device__ __forceinline__ float pymod(float a, float p) {
-    float m = ::fmodf(a, p);
-    if (m != 0.0f && ((m < 0.0f) != (p < 0.0f))) m += p;
-    return m;
+__device__ __forceinline__ void sincos_repair_r(float x, float& s, float& c) {
+    if (__builtin_expect(fabsf(x) > kFastTrigLimitF32, 0)) ::sincosf(x, &s, &c);
+}
+template <typename T>
+__device__ __forceinline__ void sincos_r(T x, T& s, T& c) {
+    sincos_fast_r(x, s, c);
+    sincos_repair_r(x, s, c);
+}
+
+// hardware reciprocal seed + Newton (emei_math.h)
+__device__ __forceinline__ double rcp_r(double d) { return refine_rcp(d, __builtin_amdgcn_rcp(d)); }
+__device__ __forceinline__ float rcp_r(float d) { return 1.0f / d; }
+
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// n / d for O(1) denominators
+__device__ __forceinline__ double div_r(double n, double d) { return n * rcp_r(d); }  // <= ~2 ulp
+__device__ __forceinline__ float div_r(float n, float d) { return n / d; }
+
+// Python / NumPy floored modulo a % p for p > 0 (np.remainder), without the library fmod loop:
+// k = floor(a/p) from a reciprocal product, remainder by one FMA (exact whenever k is the true
+// quotient, because the exact remainder is representable), one-period fix-up when k is off by one.
+template <typename T>
+__device__ __forceinline__ T pymod_pos(T a, T p, T inv_p) {
+    T k = floor(a * inv_p);
+    T w = fma_r(-k, p, a);
+    if (w < T(0)) w += p;
+    else if (w >= p) w -= p;
+    return w;
 }
 
 template <typename T>
@@ -44,11 +69,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t env, uint
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0;
-        uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0, c1 = lo1, c2 = n2, c3 = lo0;
+        // one full 32x32->64 product per multiplier (v_mad_u64_u32) instead of mul_hi + mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0, c1 = (uint32_t)p1, c2 = n2, c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

@@ -39,35 +39,65 @@ struct CartPole {
     struct Carry {
         R sn, cs;
     };
-    using Action = R;  // the force
+    using Action = R;  // force / total_mass
+    // only the float32 time step reaches the kernel: a small argument block leaves the scalar
+    // registers to the polynomial constants of sincos (otherwise they are copied through VGPRs)
+    struct Params {
+        float dt32;
+    };
+    static Params make_params(const PendParams& p) { return Params{p.dt32}; }
 
-    __device__ __forceinline__ static Action load_action(const void* p, int dtype, int64_t idx) {
+    using RawAction = int;
+    __device__ __forceinline__ static RawAction load_raw(const void* p, int dtype, int64_t idx) {
+        return load_discrete_action(p, dtype, idx);
+    }
+    template <typename T>
+    __device__ __forceinline__ static Action decode_t(T a) {
+        return a == T(1) ? R(10.0 / 1.1) : R(-10.0 / 1.1);
+    }
+    __device__ __forceinline__ static Action decode(RawAction a) {
         // _extract_action, cartpole.py:121-122,142-143: +force_mag if action == 1 else -force_mag
-        return load_discrete_action(p, dtype, idx) == 1 ? R(10.0) : R(-10.0);
+        // folded with the division by total_mass (cartpole.py:54): +-force_mag / total_mass
+        return a == 1 ? R(10.0 / 1.1) : R(-10.0 / 1.1);
+    }
+    __device__ __forceinline__ static Action load_action(const void* p, int dtype, int64_t idx) {
+        return decode(load_raw(p, dtype, idx));
     }
 
-    __device__ __forceinline__ static void prime(const R s[4], Carry& c, const PendParams&) {
+    __device__ __forceinline__ static void prime(const R s[4], Carry& c, const Params&) {
         sincos_r(s[2], c.sn, c.cs);
     }
 
     // One explicit-Euler substep: cartpole.py:48-60 (_dsdt) + base_control.py:162-164.
-    // The expression order is the reference's; the build compiles with -ffp-contract=off so that
-    // no product/sum is fused behind its back.
-    __device__ __forceinline__ static void substep(R s[4], Carry& c, R force, const PendParams& p) {
-        const R gravity = R(9.8), mass_pole = R(0.1), total_mass = R(0.1) + R(1.0), length = R(0.5);
-        const R pole_mass_length = mass_pole * length;
-        R x_dot = s[1], theta_dot = s[3];
-        R temp = (force + pole_mass_length * (theta_dot * theta_dot) * c.sn) / total_mass;
-        R theta_acc = (gravity * c.sn - c.cs * temp) /
-                      (length * (R(4.0) / R(3.0) - mass_pole * (c.cs * c.cs) / total_mass));
-        R x_acc = temp - pole_mass_length * theta_acc * c.cs / total_mass;
-        // derivative rounded to float32 (cartpole.py:60), float32 product with float32(dt), then
-        // accumulated in R (float64 in the reference)
+    //   temp      = (force + pml*thd^2*sin) / M
+    //   theta_acc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M))
+    //   x_acc     = temp - pml*theta_acc*cos / M
+    // The three divisions by the constant total mass are folded into constants and the one true
+    // division uses a refined hardware reciprocal: a few ulp of the working precision away from the
+    // reference's expression order, far below the float32 rounding the reference applies to the
+    // derivative next (cartpole.py:60).
+    __device__ __forceinline__ static void substep(R s[4], Carry& c, R force_over_m, const Params& p) {
+        const R A = R(0.1 * 0.5 / 1.1);        // pole_mass_length / total_mass
+        const R B = R(0.5 * 0.1 / 1.1);        // length * mass_pole / total_mass
+        const R L43 = R(0.5 * 4.0 / 3.0);      // length * 4/3
+        const R gravity = R(9.8);
+        const R x_dot = s[1], theta_dot = s[3];
+        // theta advances with the OLD theta_dot only, so its new sin/cos does not wait for the
+        // accelerations: issue it first and let it overlap the dynamics below
         s[0] += (R)__fmul_rn((float)x_dot, p.dt32);
-        s[1] += (R)__fmul_rn((float)x_acc, p.dt32);
         s[2] += (R)__fmul_rn((float)theta_dot, p.dt32);
+        const R sn = c.sn, cs = c.cs;
+        sincos_fast_r(s[2], c.sn, c.cs);
+        R temp = fma_r(A * (theta_dot * theta_dot), sn, force_over_m);
+        R num = fma_r(gravity, sn, -(cs * temp));
+        R den = fma_r(-B, cs * cs, L43);
+        R theta_acc = div_r(num, den);
+        R x_acc = fma_r(-(A * theta_acc), cs, temp);
+        // derivative rounded to float32 (cartpole.py:60), float32 product with float32(dt)
+        // (base_control.py:164, weak-scalar promotion), accumulated in R (float64 in the reference)
+        s[1] += (R)__fmul_rn((float)x_acc, p.dt32);
         s[3] += (R)__fmul_rn((float)theta_acc, p.dt32);
-        sincos_r(s[2], c.sn, c.cs);
+        sincos_repair_r(s[2], c.sn, c.cs);  // |theta| > 1e6 only; after the straight-line block
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
@@ -75,11 +105,11 @@ struct CartPole {
     }
 
     // reward / terminal from the carry of the NEW state
-    __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const PendParams&) {
-        if (VARIANT == 0) return (c.cs + R(1)) / R(2);  // cartpole.py:149-151
+    __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const Params&) {
+        if (VARIANT == 0) return (R)__builtin_fmaf((float)c.cs, 0.5f, 0.5f);  // (cos+1)/2, cartpole.py:149-151
         return R(1);                                     // cartpole.py:128-129
     }
-    __device__ __forceinline__ static bool terminal(const R o[4], const Carry&, const PendParams&) {
+    __device__ __forceinline__ static bool terminal(const R o[4], const Carry&, const Params&) {
         if (VARIANT == 0) {
             bool notdone = fabs(o[0]) < R(5);  // cartpole.py:140,145-147
             return !notdone;
@@ -89,7 +119,7 @@ struct CartPole {
         return !notdone;
     }
 
-    __device__ __forceinline__ static void step(R s[4], Carry& c, Action force, const PendParams& p, int freq_rate,
+    __device__ __forceinline__ static void step(R s[4], Carry& c, Action force, const Params& p, int freq_rate,
                                                 R o[4], R& rew, bool& term) {
         for (int k = 0; k < freq_rate; ++k) substep(s, c, force, p);  // base_control.py:73,162-164
         obs_of(s, o);
@@ -99,7 +129,7 @@ struct CartPole {
 
     // device reset: U(-0.05,0.05)^4, SwingUp theta += pi (cartpole.py:131-132,153-156)
     __device__ __forceinline__ static void init(R s[4], uint64_t seed, uint64_t env, uint32_t episode,
-                                                const PendParams&) {
+                                                const Params&) {
         u32x4 r = philox4x32_10(seed, env, episode, 0);
         float f[4];
 #pragma unroll
@@ -126,10 +156,20 @@ struct InvPend {
         R sn, cs;  // of phi = theta + phi_off
     };
     using Action = R;  // clipped ctrl
+    using Params = PendParams;
+    static Params make_params(const PendParams& p) { return p; }
 
+    using RawAction = float;
+    __device__ __forceinline__ static RawAction load_raw(const void* p, int dtype, int64_t idx) {
+        return (dtype == EMEI_ACT_F32) ? ((const float*)p)[idx] : (float)load_discrete_action(p, dtype, idx);
+    }
+    __device__ __forceinline__ static Action decode(RawAction a) { return (R)a; }
+    template <typename T>
+    __device__ __forceinline__ static Action decode_t(T a) {
+        return (R)a;
+    }
     __device__ __forceinline__ static Action load_action(const void* p, int dtype, int64_t idx) {
-        R a = (dtype == EMEI_ACT_F32) ? (R)((const float*)p)[idx] : (R)load_discrete_action(p, dtype, idx);
-        return a;
+        return decode(load_raw(p, dtype, idx));
     }
 
     __device__ __forceinline__ static void prime(const R s[4], Carry& c, const PendParams& p) {
@@ -142,9 +182,10 @@ struct InvPend {
         R ctrl = u < (R)p.ctrl_lo ? (R)p.ctrl_lo : (u > (R)p.ctrl_hi ? (R)p.ctrl_hi : u);  // ctrllimited
         R f1 = (R)p.gear * ctrl + (R)p.mpr * c.sn * s[3] * s[3];
         R f2 = (R)p.mgr * c.sn;
-        R det = M11 * M22 - M12 * M12;
-        R a0 = (M22 * f1 - M12 * f2) / det;
-        R a1 = (M11 * f2 - M12 * f1) / det;
+        R det = fma_r(-M12, M12, M11 * M22);
+        R idet = rcp_r(det);
+        R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
+        R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
         // soft slider-limit constraint (MuJoCo joint limit, default solref/solimp)
         R dist = R(0), J = R(0);
         if (s[0] - (R)p.x_lo < R(0)) {
@@ -160,26 +201,26 @@ struct InvPend {
             R K = R(1) / ((R)p.dmax * (R)p.dmax * tc * tc * (R)p.dampratio * (R)p.dampratio);
             R B = R(2) / ((R)p.dmax * tc);
             R aref = -B * (J * s[2]) - K * imp * dist;
-            R A = M22 / det;
+            R A = M22 * idet;
             R Rr = (R(1) - imp) / imp * (R)p.invw;
             R force = (aref - J * a0) / (A + Rr);
             if (force > R(0)) {
-                a0 += (M22 / det) * J * force;
-                a1 += (-M12 / det) * J * force;
+                a0 += (M22 * idet) * J * force;
+                a1 += (-M12 * idet) * J * force;
             }
         }
         R dt = (R)p.dt;
-        R q0 = s[0] + dt * s[2], q1 = s[1] + dt * s[3];  // get_euler_pos, mujoco_env.py:189-191
-        s[2] += dt * a0;                                  // MuJoCo Euler on qvel (no damping here)
-        s[3] += dt * a1;
-        s[0] = q0, s[1] = q1;
+        s[0] = fma_r(dt, s[2], s[0]);  // get_euler_pos, mujoco_env.py:189-191: old velocity
+        s[1] = fma_r(dt, s[3], s[1]);
+        s[2] = fma_r(dt, a0, s[2]);    // MuJoCo Euler on qvel (no joint damping in this model)
+        s[3] = fma_r(dt, a1, s[3]);
         sincos_r(s[1] + (R)p.phi_off, c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
         const R pi = R(3.141592653589793);
         o[0] = s[0];
-        o[1] = pymod(s[1] + pi, R(2) * pi) - pi;  // inverted_pendulum.py:45-49
+        o[1] = pymod_pos(s[1] + pi, R(2) * pi, R(1.0 / (2 * 3.141592653589793))) - pi;  // inverted_pendulum.py:45-49
         o[2] = s[2], o[3] = s[3];
     }
 

@@ -26,17 +26,21 @@ struct RolloutArgs {
     int32_t n_steps, freq_rate, action_dtype, max_episode_steps;
     uint32_t flags;
     uint64_t seed, env_offset;
-    PendParams p;
+    typename Env::Params p;
 };
 
 // emei_step (n_steps = 1) and emei_rollout (n_steps = T): base_control.py:61-83 /
 // mujoco_env.py:157-167 for every env of the shard, T times, without leaving the registers.
-template <class Env>
+// FULL = all three outputs are non-null: the stores are then unconditional, which lets the compiler
+// count them and wait for a chunk's action loads with vmcnt(3*kChunk) instead of vmcnt(0).
+template <class Env, typename ActT, bool FULL>
 __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<Env> a) {
     using R = typename Env::real;
+    const ActT* __restrict__ actions = (const ActT*)a.actions;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
     const int64_t n = a.n;
+    const uint32_t li = (uint32_t)i;  // n_envs < 2^31 (checked in emei_create)
 
     R s[4];
 #pragma unroll
@@ -47,24 +51,34 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
     Env::prime(s, c, a.p);
 
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
-    typename Env::Action act_next = Env::load_action(a.actions, a.action_dtype, i);
+    // Actions are fetched a whole chunk of kChunk steps ahead of their use.  On gfx950 loads and
+    // stores share one in-order counter (vmcnt), so waiting for a load also waits for every OLDER
+    // store: with the loads issued one chunk early, the only stores older than them were issued
+    // >= kChunk steps ago and have long retired, and the 3*kChunk stores of the current chunk stay in
+    // flight behind the wait.  (Fetching one step ahead put the HBM write latency of the previous
+    // step's stores on the serial per-env chain: 2.3x slower.)
+    // The action dtype is a template parameter and out-of-range steps are clamped rather than
+    // branched around, so the kChunk loads are one straight-line burst and the compiler can count
+    // them (a dtype switch around each load made it fall back to vmcnt(0) after every load).
+    constexpr int kChunk = 8;
+    const int last = a.n_steps - 1;
+    ActT cur[kChunk], nxt[kChunk];
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) cur[j] = (actions + (int64_t)min(j, last) * n)[li];
     uint32_t done = 0;
-    for (int t = 0; t < a.n_steps; ++t) {
-        typename Env::Action act = act_next;
-        if (t + 1 < a.n_steps)  // prefetch the next action under this step's arithmetic
-            act_next = Env::load_action(a.actions, a.action_dtype, (int64_t)(t + 1) * n + i);
-
+    auto do_step = [&](int t, ActT raw) __attribute__((always_inline)) {
         R o[4], rew;
         bool term;
-        Env::step(s, c, act, a.p, a.freq_rate, o, rew, term);
+        Env::step(s, c, Env::decode_t(raw), a.p, a.freq_rate, o, rew, term);
         ++steps;
         bool trunc = (a.max_episode_steps > 0) & (steps >= a.max_episode_steps);
         done = (term ? EMEI_DONE_TERMINAL : 0u) | (trunc ? EMEI_DONE_TRUNCATED : 0u);
 
-        const int64_t off = (int64_t)t * n + i;
-        if (a.obs_out) a.obs_out[off] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-        if (a.reward_out) a.reward_out[off] = (float)rew;
-        if (a.done_out) a.done_out[off] = (uint8_t)done;
+        // uniform (scalar) row base + 32-bit lane index: the address costs no vector instruction
+        const int64_t row = (int64_t)t * n;
+        if (FULL || a.obs_out) (a.obs_out + row)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        if (FULL || a.reward_out) (a.reward_out + row)[li] = (float)rew;
+        if (FULL || a.done_out) (a.done_out + row)[li] = (uint8_t)done;
 
         // early-termination handling: the reset path (Philox + a fresh sincos) is skipped by the
         // whole wave unless the ballot says some lane is done
@@ -76,6 +90,23 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
                 Env::prime(s, c, a.p);
             }
         }
+    };
+    int t0 = 0;
+    // full chunks: no per-step bounds check, so every path through the body issues exactly
+    // 3*kChunk stores after the prefetch and the wait for it can leave them all in flight
+    for (; t0 + kChunk <= a.n_steps; t0 += kChunk) {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) nxt[j] = (actions + (int64_t)min(t0 + kChunk + j, last) * n)[li];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) do_step(t0 + j, cur[j]);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) cur[j] = nxt[j];
+    }
+    // tail (< kChunk steps); also the whole of emei_step (n_steps = 1)
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        if (t0 + j >= a.n_steps) break;
+        do_step(t0 + j, cur[j]);
     }
 
 #pragma unroll
@@ -87,11 +118,162 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
     if ((threadIdx.x & (kWave - 1)) == 0) a.done_mask[i / kWave] = m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staged rollout: the fast path of emei_rollout (all outputs present, n a multiple of 64,
+// 16-byte aligned buffers).  Same arithmetic and results as pend_rollout_kernel; what changes is
+// how bytes move.  A wave owns 64 consecutive envs, i.e. a 64-column stripe of the [T, N] action,
+// reward and done arrays, and stages kStage = 16 steps of that stripe through its private slice of
+// LDS so that every global access is a full 16 B per lane:
+//   actions : one global_load_dwordx4 per lane and sizeof(ActT) fetches a 16-step tile, LDS holds it
+//             row-major, each step reads its own element back (ds_read, lgkm counter: the wait no
+//             longer sits behind the stores, which share vmcnt with loads on gfx950)
+//   reward  : ds_write_b32 per step; every 4 steps one ds_read_b128 + global_store_dwordx4 (4 rows)
+//   done    : ds_write_b8 per step; every 16 steps one ds_read_b128 + global_store_dwordx4 (16 rows)
+//   obs     : already 16 B per lane, stored directly
+// => 1.31 vector stores + 1/16 loads per env-step instead of 3 stores + 1 load, and no 64 B
+// partial-line byte stores.  LDS slices are wave-private (LDS operations of one wave execute in
+// order), so there is no barrier anywhere.
+constexpr int kStage = 16;
+
+template <class Env, typename ActT, bool FREQ1>
+__global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
+    using R = typename Env::real;
+    constexpr int kWavesPerBlock = kBlock / kWave;
+    constexpr int kActVec = sizeof(ActT);  // 16-byte vectors per lane for a 16x64 tile of ActT
+    __shared__ uint4 act_s[kWavesPerBlock][2][kStage * kWave * sizeof(ActT) / 16];
+    __shared__ float rew_s[kWavesPerBlock][4][kWave];
+    __shared__ uint8_t done_s[kWavesPerBlock][kStage][kWave];
+
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
+    if (i >= a.n) return;
+    const int64_t n = a.n;
+    const uint32_t li = (uint32_t)i, i0 = li - (uint32_t)lane;
+    const ActT* __restrict__ actions = (const ActT*)a.actions;
+
+    R s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = a.state[k * n + i];
+    int32_t steps = a.steps[i];
+    uint32_t episode = a.episode[i];
+    typename Env::Carry c;
+    Env::prime(s, c, a.p);
+    const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
+    const int last = a.n_steps - 1;
+    uint32_t done = 0;
+
+    // tile geometry of one 16-byte vector v (0..kActVec-1) of this lane inside a 16-step tile
+    constexpr int kLanesPerRow = kWave * sizeof(ActT) / 16;  // lanes that cover one 64-env row
+    constexpr int kRowsPerVec = kWave / kLanesPerRow;        // rows one wave-wide vector load covers
+    const int rsub = lane / kLanesPerRow, cbyte = (lane % kLanesPerRow) * 16;
+    auto load_tile = [&](int t0, uint4 (&v)[kActVec]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < kActVec; ++k) {
+            const int row = min(t0 + k * kRowsPerVec + rsub, last);  // clamp: never read past step T-1
+            const char* src = (const char*)(actions + (int64_t)row * n + i0) + cbyte;
+            v[k] = *(const uint4*)src;
+        }
+    };
+    auto stash_tile = [&](int buf, const uint4 (&v)[kActVec]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < kActVec; ++k) act_s[wv][buf][k * kWave + lane] = v[k];
+    };
+
+    // FREQ1: freq_rate == 1 is resolved at compile time (no substep loop, no loop branches: every
+    // taken branch costs a lone wave an instruction-buffer refill)
+    const int freq_rate = FREQ1 ? 1 : a.freq_rate;
+    auto advance = [&](ActT raw, R (&o)[4], R& rew) __attribute__((always_inline)) {
+        bool term;
+        Env::step(s, c, Env::decode_t(raw), a.p, freq_rate, o, rew, term);
+        ++steps;
+        bool trunc = (a.max_episode_steps > 0) & (steps >= a.max_episode_steps);
+        done = (term ? EMEI_DONE_TERMINAL : 0u) | (trunc ? EMEI_DONE_TRUNCATED : 0u);
+    };
+    auto maybe_reset = [&]() __attribute__((always_inline)) {
+        // cold: laid out of line so that the usual case falls through
+        if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
+            if (done != 0) {
+                ++episode;
+                steps = 0;
+                Env::init(s, a.seed, a.env_offset + (uint64_t)i, episode, a.p);
+                Env::prime(s, c, a.p);
+            }
+        }
+    };
+    auto store_rew_rows = [&](int64_t row0, const float4& v) __attribute__((always_inline)) {
+        float* dst = a.reward_out + (row0 + (lane >> 4)) * n + i0 + ((lane & 15) << 2);
+        *(float4*)dst = v;
+    };
+    auto store_done_rows = [&](int64_t row0, const uint4& v) __attribute__((always_inline)) {
+        uint8_t* dst = a.done_out + (row0 + (lane >> 2)) * n + i0 + ((lane & 3) << 4);
+        *(uint4*)dst = v;
+    };
+
+    uint4 tile[kActVec];
+    load_tile(0, tile);
+    stash_tile(0, tile);
+    int t0 = 0, buf = 0;
+    // The LDS read of a flush is issued at the end of one step and its global store after the
+    // arithmetic of the NEXT step (each step is its own scheduling region because of the reset
+    // check, so a read placed next to its use would expose the LDS latency on the serial chain).
+    // Which step flushes what is known at compile time inside the unrolled tile; only the hand-over
+    // from the previous tile (step 0) is a run-time, wave-uniform condition.
+    float4 rew_pend = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 done_pend = make_uint4(0u, 0u, 0u, 0u);
+    for (; t0 + kStage <= a.n_steps; t0 += kStage, buf ^= 1) {
+        load_tile(t0 + kStage, tile);  // next tile: in flight under the 16 steps below
+        const ActT* act_l = (const ActT*)&act_s[wv][buf][0];
+        ActT acts[kStage];
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) acts[j] = act_l[j * kWave + lane];
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            R o[4], rew;
+            advance(acts[j], o, rew);
+            (a.obs_out + (int64_t)(t0 + j) * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+            if (j == 0) {
+                if (t0 > 0) {  // rows staged by the last steps of the previous tile
+                    store_rew_rows(t0 - 4, rew_pend);
+                    store_done_rows(t0 - kStage, done_pend);
+                }
+            } else if ((j & 3) == 0) {
+                store_rew_rows(t0 + j - 4, rew_pend);
+            }
+            rew_s[wv][j & 3][lane] = (float)rew;
+            done_s[wv][j][lane] = (uint8_t)done;
+            if ((j & 3) == 3) rew_pend = ((const float4*)&rew_s[wv][0][0])[lane];           // 4 rows x 256 B
+            if (j == kStage - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];       // 16 rows x 64 B
+            maybe_reset();
+        }
+        stash_tile(buf ^ 1, tile);
+    }
+    if (t0 > 0) {
+        store_rew_rows(t0 - 4, rew_pend);
+        store_done_rows(t0 - kStage, done_pend);
+    }
+    // tail (< 16 steps): direct loads and stores
+    for (int t = t0; t < a.n_steps; ++t) {
+        R o[4], rew;
+        advance((actions + (int64_t)t * n)[li], o, rew);
+        (a.obs_out + (int64_t)t * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        (a.reward_out + (int64_t)t * n)[li] = (float)rew;
+        (a.done_out + (int64_t)t * n)[li] = (uint8_t)done;
+        maybe_reset();
+    }
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.state[k * n + i] = s[k];
+    a.steps[i] = steps;
+    a.episode[i] = episode;
+    unsigned long long m = __ballot(done != 0);
+    if (lane == 0) a.done_mask[i / kWave] = m;
+}
+
 // Env.reset on the device
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
     pend_reset_kernel(typename Env::real* state, int32_t* steps, uint32_t* episode, int64_t n, uint64_t seed,
-                      uint64_t env_offset, PendParams p) {
+                      uint64_t env_offset, typename Env::Params p) {
     using R = typename Env::real;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -124,7 +306,8 @@ __global__ void __launch_bounds__(kBlock)
 // get_batch_reward / get_batch_terminal (core.py:182-188)
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
-    pend_reward_terminal_kernel(const float4* obs, float* reward, uint8_t* terminal, int64_t n, PendParams p) {
+    pend_reward_terminal_kernel(const float4* obs, float* reward, uint8_t* terminal, int64_t n,
+                                typename Env::Params p) {
     using R = typename Env::real;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -142,7 +325,7 @@ __global__ void __launch_bounds__(kBlock)
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
     pend_next_obs_kernel(const float4* obs, const void* actions, int action_dtype, float4* next_obs, int64_t n,
-                         int freq_rate, PendParams p) {
+                         int freq_rate, typename Env::Params p) {
     using R = typename Env::real;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -156,6 +339,25 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---------------------------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <class Env, typename ActT>
+static void launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
+    const bool full = a.obs_out && a.reward_out && a.done_out;
+    if (full && a.n_steps >= kStage && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
+        aligned16(a.reward_out) && aligned16(a.done_out))
+    {
+        if (a.freq_rate == 1)
+            hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+    }
+    else if (full)
+        hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+}
+
 // host-side dispatch over (env id, precision)
 template <template <int, typename> class Fam, int V, typename R>
 static int launch_rollout_t(const PendLaunch& L) {
@@ -177,15 +379,24 @@ static int launch_rollout_t(const PendLaunch& L) {
     a.flags = L.flags;
     a.seed = L.seed;
     a.env_offset = L.env_offset;
-    a.p = L.p;
+    a.p = Env::make_params(L.p);
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case PEND_OP_ROLLOUT:
-            hipLaunchKernelGGL(pend_rollout_kernel<Env>, grid, dim3(kBlock), 0, L.stream, a);
+            // discrete envs take uint8/int32/int64 actions, continuous envs float32
+            if (Env::kDiscrete) {
+                if (L.action_dtype == EMEI_ACT_U8) launch_rollout_full<Env, uint8_t>(a, grid, L.stream);
+                else if (L.action_dtype == EMEI_ACT_I32) launch_rollout_full<Env, int32_t>(a, grid, L.stream);
+                else if (L.action_dtype == EMEI_ACT_I64) launch_rollout_full<Env, int64_t>(a, grid, L.stream);
+                else return EMEI_ERR_INVALID;
+            } else {
+                if (L.action_dtype != EMEI_ACT_F32) return EMEI_ERR_INVALID;
+                launch_rollout_full<Env, float>(a, grid, L.stream);
+            }
             break;
         case PEND_OP_RESET:
             hipLaunchKernelGGL(pend_reset_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps,
-                               L.episode, L.n, L.seed, L.env_offset, L.p);
+                               L.episode, L.n, L.seed, L.env_offset, a.p);
             break;
         case PEND_OP_GET_OBS:
             hipLaunchKernelGGL(pend_get_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (const R*)L.state,
@@ -193,11 +404,11 @@ static int launch_rollout_t(const PendLaunch& L) {
             break;
         case PEND_OP_REWARD_TERMINAL:
             hipLaunchKernelGGL(pend_reward_terminal_kernel<Env>, grid, dim3(kBlock), 0, L.stream,
-                               (const float4*)L.obs_in, L.reward_out, L.done_out, L.n, L.p);
+                               (const float4*)L.obs_in, L.reward_out, L.done_out, L.n, a.p);
             break;
         case PEND_OP_NEXT_OBS:
             hipLaunchKernelGGL(pend_next_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (const float4*)L.obs_in,
-                               L.actions, L.action_dtype, (float4*)L.obs_out, L.n, L.freq_rate, L.p);
+                               L.actions, L.action_dtype, (float4*)L.obs_out, L.n, L.freq_rate, a.p);
             break;
         default: return EMEI_ERR_INVALID;
     }
@@ -210,6 +421,12 @@ static int launch_prec(const PendLaunch& L) {
 }
 
 int pend_launch(const PendLaunch& L) {
+#ifdef EMEI_DEV_SUBSET  // fast-iteration build: CartPole only
+    switch (L.env_id) {
+        case EMEI_CARTPOLE_SWINGUP: return launch_prec<CartPole, 0>(L);
+        default: return EMEI_ERR_UNSUPPORTED;
+    }
+#else
     switch (L.env_id) {
         case EMEI_CARTPOLE_SWINGUP: return launch_prec<CartPole, 0>(L);
         case EMEI_CARTPOLE_BALANCING: return launch_prec<CartPole, 1>(L);
@@ -219,6 +436,7 @@ int pend_launch(const PendLaunch& L) {
         case EMEI_IP_BOUNDARY_SWINGUP: return launch_prec<InvPend, 3>(L);
         default: return EMEI_ERR_UNSUPPORTED;
     }
+#endif
 }
 
 }  // namespace emei
