@@ -1,4 +1,4 @@
-// pendulum_kernels.hip — step / rollout kernels of the 4-state cart/pole family for gfx950.
+// pendulum_kernels.h — step / rollout kernels of the 4-state cart/pole family for gfx950.
 //
 // Layout: one thread per env instance; state is struct-of-arrays in HBM (4 arrays of n Reals + a
 // step counter and an episode counter per env), so every state access of a wave is one fully
@@ -7,6 +7,7 @@
 // the carried sin/cos and the counters in registers for all n_steps; per step it reads one action
 // and writes obs + reward + done (22 B/env-step with uint8 actions).
 // There is no dense contraction anywhere on this path, hence no MFMA: the roofline is HBM.
+#pragma once
 #include "pendulum_envs.h"
 #include "launch.h"
 
@@ -166,18 +167,25 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     constexpr int kLanesPerRow = kWave * sizeof(ActT) / 16;  // lanes that cover one 64-env row
     constexpr int kRowsPerVec = kWave / kLanesPerRow;        // rows one wave-wide vector load covers
     const int rsub = lane / kLanesPerRow, cbyte = (lane % kLanesPerRow) * 16;
-    auto load_tile = [&](int t0, uint4 (&v)[kActVec]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < kActVec; ++k) {
-            const int row = min(t0 + k * kRowsPerVec + rsub, last);  // clamp: never read past step T-1
-            const char* src = (const char*)(actions + (int64_t)row * n + i0) + cbyte;
-            v[k] = *(const uint4*)src;
-        }
-    };
-    auto stash_tile = [&](int buf, const uint4 (&v)[kActVec]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < kActVec; ++k) act_s[wv][buf][k * kWave + lane] = v[k];
-    };
+    const char* act_lane_base = (const char*)(actions + i0) + cbyte;  // this lane's column inside a row
+    const int64_t act_row_bytes = n * (int64_t)sizeof(ActT);
+    // Action tiles go global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): one wave-instruction
+    // writes 1 KiB of LDS linearly (lane l -> base + 16 l), which is exactly the row-major tile image,
+    // and no VGPR carries the tile across the 16 steps it is in flight (held in registers, hipcc
+    // parked it in scratch and stalled on the load at once).  hipcc does not count asm memory
+    // operations, so the wait that retires a tile is written out below (EMEI_TILE_WAIT).
+    const uint32_t act_lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&act_s[wv][0][0]);
+    constexpr uint32_t kTileBytes = kStage * kWave * sizeof(ActT);
+#define EMEI_LOAD_TILE(T0, BUF)                                                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < kActVec; ++k_) {                                             \
+        const int row_ = min((T0) + k_ * kRowsPerVec + rsub, last); /* never read past step T-1 */        \
+        const char* src_ = act_lane_base + row_ * act_row_bytes;                                          \
+        const uint32_t dst_ = act_lds0 + (uint32_t)(BUF) * kTileBytes + (uint32_t)k_ * 1024u;              \
+        uint32_t keep_;                                                                                   \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                    \
+    }
 
     // FREQ1: freq_rate == 1 is resolved at compile time (no substep loop, no loop branches: every
     // taken branch costs a lone wave an instruction-buffer refill)
@@ -200,18 +208,19 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
             }
         }
     };
+    // per-lane element offsets inside a flushed block of rows, computed once (the per-step address
+    // is then a scalar row base plus this constant: no 64-bit vector multiply on the hot path)
+    const int64_t rew_lane_off = (int64_t)(lane >> 4) * n + i0 + ((lane & 15) << 2);  // 16 lanes x 16 B per row
+    const int64_t done_lane_off = (int64_t)(lane >> 2) * n + i0 + ((lane & 3) << 4);  // 4 lanes x 16 B per row
     auto store_rew_rows = [&](int64_t row0, const float4& v) __attribute__((always_inline)) {
-        float* dst = a.reward_out + (row0 + (lane >> 4)) * n + i0 + ((lane & 15) << 2);
-        *(float4*)dst = v;
+        *(float4*)(a.reward_out + row0 * n + rew_lane_off) = v;
     };
     auto store_done_rows = [&](int64_t row0, const uint4& v) __attribute__((always_inline)) {
-        uint8_t* dst = a.done_out + (row0 + (lane >> 2)) * n + i0 + ((lane & 3) << 4);
-        *(uint4*)dst = v;
+        *(uint4*)(a.done_out + row0 * n + done_lane_off) = v;
     };
 
-    uint4 tile[kActVec];
-    load_tile(0, tile);
-    stash_tile(0, tile);
+    EMEI_LOAD_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t0 = 0, buf = 0;
     // The LDS read of a flush is issued at the end of one step and its global store after the
     // arithmetic of the NEXT step (each step is its own scheduling region because of the reset
@@ -221,15 +230,16 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     float4 rew_pend = make_float4(0.f, 0.f, 0.f, 0.f);
     uint4 done_pend = make_uint4(0u, 0u, 0u, 0u);
     for (; t0 + kStage <= a.n_steps; t0 += kStage, buf ^= 1) {
-        load_tile(t0 + kStage, tile);  // next tile: in flight under the 16 steps below
+        EMEI_LOAD_TILE(t0 + kStage, buf ^ 1)  // next tile: in flight under the 16 steps below
         const ActT* act_l = (const ActT*)&act_s[wv][buf][0];
-        ActT acts[kStage];
-#pragma unroll
-        for (int j = 0; j < kStage; ++j) acts[j] = act_l[j * kWave + lane];
+        ActT act_cur = act_l[lane];
 #pragma unroll
         for (int j = 0; j < kStage; ++j) {
+            // the next step's action leaves LDS while this step computes
+            const ActT act_now = act_cur;
+            if (j + 1 < kStage) act_cur = act_l[(j + 1) * kWave + lane];
             R o[4], rew;
-            advance(acts[j], o, rew);
+            advance(act_now, o, rew);
             (a.obs_out + (int64_t)(t0 + j) * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
             if (j == 0) {
                 if (t0 > 0) {  // rows staged by the last steps of the previous tile
@@ -245,7 +255,9 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
             if (j == kStage - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];       // 16 rows x 64 B
             maybe_reset();
         }
-        stash_tile(buf ^ 1, tile);
+        // retire the tile: it is older than this tile's stores (16 obs + >= 3 reward flushes), so
+        // leaving the 19 youngest operations in flight still covers every LDS-DMA load
+        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
     }
     if (t0 > 0) {
         store_rew_rows(t0 - 4, rew_pend);
@@ -267,6 +279,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     a.episode[i] = episode;
     unsigned long long m = __ballot(done != 0);
     if (lane == 0) a.done_mask[i / kWave] = m;
+#undef EMEI_LOAD_TILE
 }
 
 // Env.reset on the device
@@ -359,9 +372,10 @@ static void launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_
 }
 
 // host-side dispatch over (env id, precision)
-template <template <int, typename> class Fam, int V, typename R>
-static int launch_rollout_t(const PendLaunch& L) {
-    using Env = Fam<V, R>;
+// every launch of one Env type (one translation unit instantiates exactly one Env: pendulum_tu.hip)
+template <class Env>
+static int launch_env(const PendLaunch& L) {
+    using R = typename Env::real;
     RolloutArgs<Env> a;
     a.state = (R*)L.state;
     a.steps = L.steps;
@@ -384,7 +398,7 @@ static int launch_rollout_t(const PendLaunch& L) {
     switch (L.op) {
         case PEND_OP_ROLLOUT:
             // discrete envs take uint8/int32/int64 actions, continuous envs float32
-            if (Env::kDiscrete) {
+            if constexpr (Env::kDiscrete) {
                 if (L.action_dtype == EMEI_ACT_U8) launch_rollout_full<Env, uint8_t>(a, grid, L.stream);
                 else if (L.action_dtype == EMEI_ACT_I32) launch_rollout_full<Env, int32_t>(a, grid, L.stream);
                 else if (L.action_dtype == EMEI_ACT_I64) launch_rollout_full<Env, int64_t>(a, grid, L.stream);
@@ -415,28 +429,5 @@ static int launch_rollout_t(const PendLaunch& L) {
     return hipGetLastError() == hipSuccess ? EMEI_OK : EMEI_ERR_HIP;
 }
 
-template <template <int, typename> class Fam, int V>
-static int launch_prec(const PendLaunch& L) {
-    return L.precision == EMEI_PRECISION_F32 ? launch_rollout_t<Fam, V, float>(L) : launch_rollout_t<Fam, V, double>(L);
-}
-
-int pend_launch(const PendLaunch& L) {
-#ifdef EMEI_DEV_SUBSET  // fast-iteration build: CartPole only
-    switch (L.env_id) {
-        case EMEI_CARTPOLE_SWINGUP: return launch_prec<CartPole, 0>(L);
-        default: return EMEI_ERR_UNSUPPORTED;
-    }
-#else
-    switch (L.env_id) {
-        case EMEI_CARTPOLE_SWINGUP: return launch_prec<CartPole, 0>(L);
-        case EMEI_CARTPOLE_BALANCING: return launch_prec<CartPole, 1>(L);
-        case EMEI_IP_REBOUND_BALANCING: return launch_prec<InvPend, 0>(L);
-        case EMEI_IP_BOUNDARY_BALANCING: return launch_prec<InvPend, 1>(L);
-        case EMEI_IP_REBOUND_SWINGUP: return launch_prec<InvPend, 2>(L);
-        case EMEI_IP_BOUNDARY_SWINGUP: return launch_prec<InvPend, 3>(L);
-        default: return EMEI_ERR_UNSUPPORTED;
-    }
-#endif
-}
 
 }  // namespace emei

@@ -1,0 +1,10 @@
+from .cartpole import BaseCartPoleEnv, CartPoleBalancingEnv, CartPoleSwingUpEnv
+from .half_cheetah import HalfCheetahRunningEnv
+from .inverted_pendulum import (
+    BaseInvertedPendulumEnv,
+    BoundaryInvertedPendulumBalancingEnv,
+    BoundaryInvertedPendulumSwingUpEnv,
+    ReboundInvertedPendulumBalancingEnv,
+    ReboundInvertedPendulumSwingUpEnv,
+)
+from .registration import REGISTRY, make, spec

@@ -1,0 +1,199 @@
+"""HipEnv — the GPU-backed base of every emei_amd env: EmeiEnv's surface on top of the C-ABI engine.
+
+``num_envs=1`` (default) behaves like the reference's single env: ``reset()`` returns
+``(np.ndarray float64 [obs_dim], {})`` and ``step(a)`` returns
+``(obs, np.float64 reward, np.bool_ terminal, truncated, {})`` (base_control.py:38-83;
+mujoco_env.py:157-167).  ``num_envs=N`` is the vectorised form: tensors on the device, shapes
+``[N, obs_dim]`` / ``[N]``.  Every computation runs in libemei_hip.so; there is no CPU path.
+"""
+from typing import Optional
+
+import numpy as np
+
+from ..core import EmeiEnv
+
+
+class HipEnv(EmeiEnv):
+    ENGINE_NAME = None  # key of emei_amd._lib.ENV_IDS
+    metadata = {"render_modes": [], "render_fps": 50}
+
+    def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler",
+                 num_envs: int = 1, precision: str = "ref", device: Optional[int] = None,
+                 max_episode_steps: Optional[int] = None, auto_reset: bool = False, init_noise: float = 0.0,
+                 env_index_offset: int = 0):
+        self.freq_rate = freq_rate
+        self.real_time_scale = real_time_scale
+        self.integrator = integrator
+        self.num_envs = int(num_envs)
+        self.precision = precision
+        self.device_index = device
+        self.max_episode_steps = int(max_episode_steps or 0)
+        self.auto_reset = bool(auto_reset)
+        self._init_noise = float(init_noise)
+        self._env_index_offset = int(env_index_offset)
+        self._engine = None
+        self._np_random = None
+        self.state = None  # `self.state is not None` after reset (base_control.py:67)
+        EmeiEnv.__init__(self, env_params=dict(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator))
+
+    # -- gym.Env plumbing the reference inherits ---------------------------------------------------
+    @property
+    def np_random(self):
+        """gym 0.26: a PCG64 Generator, re-seeded by reset(seed=...)."""
+        if self._np_random is None:
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence()))
+        return self._np_random
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def dt(self):
+        """gym MujocoEnv.dt = timestep * frame_skip."""
+        return self.real_time_scale * self.freq_rate
+
+    def render(self):
+        raise NotImplementedError("rendering (pygame / MuJoCo viewer) is outside the env-step path")
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    # -- engine -------------------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            from ..engine import Engine  # raises loudly when the HIP library or a GPU is missing
+
+            self._engine = Engine(self.ENGINE_NAME, self.num_envs, freq_rate=self.freq_rate,
+                                  real_time_scale=self.real_time_scale, precision=self.precision,
+                                  max_episode_steps=self.max_episode_steps, device=self.device_index,
+                                  env_index_offset=self._env_index_offset, init_noise=self._init_noise)
+        return self._engine
+
+    def _host_init_state(self, batch_size) -> np.ndarray:
+        """[B, state_dim] float64 initial states drawn the way the reference draws them."""
+        raise NotImplementedError
+
+    def _state_to_obs_np(self, state: np.ndarray) -> np.ndarray:
+        return state.copy()
+
+    # -- reset / step -------------------------------------------------------------------------------
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        if seed is not None:
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        if options and options.get("device_rng"):
+            # perf path: counter-based generator on the device, no host round trip
+            self.engine.reset(0 if seed is None else seed)
+            self.state = True
+            return (self._obs_single() if self.num_envs == 1 else self.engine.get_obs()), {}
+        init = self._host_init_state(self.num_envs)
+        self.engine.set_state(init)
+        self.state = True
+        if self.num_envs == 1:
+            return self._state_to_obs_np(init)[0], {}
+        return self.engine.get_obs(), {}
+
+    def _obs_single(self):
+        return self.engine.get_obs()[0].cpu().numpy()
+
+    def _check_single_action(self, action):
+        raise NotImplementedError
+
+    def step(self, action):
+        import torch
+
+        assert self.state is not None, "Call reset before using step method."  # base_control.py:67
+        eng = self.engine
+        if self.num_envs == 1 and not isinstance(action, torch.Tensor):
+            act = self._check_single_action(action)
+            a = torch.as_tensor(act, device=eng.device).reshape((1,) if eng.act_dim <= 1 else (1, eng.act_dim))
+            _, rew, done = eng.step(a.contiguous(), auto_reset=self.auto_reset)
+            d = int(done.item())
+            obs = self._obs_single() if not (self.auto_reset and d) else _.double()[0].cpu().numpy()
+            return obs, np.float64(rew.item()), np.bool_(d & 1), bool(d & 2), {}
+        a = action if isinstance(action, torch.Tensor) else torch.as_tensor(action)
+        a = a.to(eng.device)
+        if eng.act_dim == 0 and a.dtype not in (torch.uint8, torch.int32, torch.int64):
+            a = a.to(torch.int64)
+        if eng.act_dim > 0:
+            a = a.to(torch.float32)
+        obs, rew, done = eng.step(a.contiguous(), auto_reset=self.auto_reset)
+        return obs, rew, (done & 1).bool(), (done & 2).bool(), {}
+
+    def rollout(self, actions, auto_reset=None):
+        """T fused steps in one launch: actions [T, N(, act_dim)] -> obs [T,N,obs_dim] f32, reward [T,N] f32,
+        terminal [T,N] bool, truncated [T,N] bool."""
+        assert self.state is not None, "Call reset before using step method."
+        obs, rew, done = self.engine.rollout(actions, auto_reset=self.auto_reset if auto_reset is None else auto_reset)
+        return obs, rew, (done & 1).bool(), (done & 2).bool()
+
+    # -- freeze / unfreeze: device-to-device snapshot of the state SoA -------------------------------
+    def freeze(self) -> None:
+        self.engine.freeze()
+        self.frozen = True
+
+    def unfreeze(self) -> None:
+        self.engine.unfreeze()
+        self.frozen = False
+
+    # -- batched functions of the EmeiEnv surface ------------------------------------------------------
+    def _to_dev(self, x, dtype=None):
+        import torch
+
+        if x is None:
+            return None
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        t = t.to(self.engine.device)
+        return t if dtype is None else t.to(dtype)
+
+    def _like(self, out, ref, np_dtype):
+        """[B] device tensor -> [B,1] in the caller's array type (the reference returns [B,1] arrays)."""
+        import torch
+
+        out = out.reshape(-1, 1)
+        if isinstance(ref, torch.Tensor):
+            return out
+        return out.cpu().numpy().astype(np_dtype)
+
+    def get_batch_reward(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
+        import torch
+
+        from .. import engine as E
+
+        o = self._to_dev(obs, torch.float32)
+        r = E.batch_reward(self.ENGINE_NAME, o, self._to_dev(pre_obs, torch.float32), self._to_dev(action, torch.float32),
+                           self.real_time_scale, self.freq_rate)
+        return self._like(r, obs, np.float64)
+
+    def get_batch_terminal(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
+        import torch
+
+        from .. import engine as E
+
+        t = E.batch_terminal(self.ENGINE_NAME, self._to_dev(obs, torch.float32))
+        return self._like(t, obs, np.bool_)
+
+    def get_batch_next_obs(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
+        """core.py:190-193 asserts `frozen` and is abstract in the reference (no env implements it);
+        here it is one kernel step from the given observations, without touching the env's own state."""
+        import torch
+
+        from .. import engine as E
+
+        assert self.frozen
+        o = self._to_dev(obs, torch.float32)
+        a = self._to_dev(action)
+        if self.engine.act_dim == 0:
+            a = a.reshape(-1).to(torch.int64)
+        else:
+            a = a.to(torch.float32).reshape(o.shape[0], -1)
+        nxt = E.batch_next_obs(self.ENGINE_NAME, o, a.contiguous(), self.real_time_scale, self.freq_rate, self.precision)
+        if isinstance(obs, torch.Tensor):
+            return nxt
+        return nxt.cpu().numpy().astype(np.float64)
+
+    def get_batch_init_state(self, batch_size):
+        return self._host_init_state(batch_size)

@@ -30,7 +30,8 @@ def rel_err(a, b, floor=1.0):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     both_nan = np.isnan(a) & np.isnan(b)
     same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
-    d = np.abs(a - b) / np.maximum(np.abs(b), floor)
+    with np.errstate(all="ignore"):
+        d = np.abs(a - b) / np.maximum(np.abs(b), floor)
     d = np.where(both_nan | same_inf, 0.0, d)
     d = np.where(np.isnan(d), np.inf, d)
     return float(d.max()) if d.size else 0.0

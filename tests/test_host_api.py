@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference's API surface: everything here runs without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import emei_amd
+from emei_amd import _lib, spaces
+from emei_amd.core import EmeiEnv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_env_params_name(mujoco_golden):
+    """test/test_core.py:9-14 of the reference."""
+    env = EmeiEnv(env_params={"a": 3, "b": 5, "d": 0.33, "c": "c"})
+    assert env.env_params_name == "a=3&b=5&c=c&d=0.33"
+    env = EmeiEnv(env_params=dict(freq_rate=1, real_time_scale=0.02))
+    assert env.env_params_name == "freq_rate=1&real_time_scale=0.02"
+    names = [str(x) for x in mujoco_golden["env_params_names"]]
+    assert names[0] == "a=3&b=5&c=c&d=0.33"
+    assert emei_amd.HalfCheetahRunningEnv().env_params_name == names[2]
+    assert emei_amd.CartPoleSwingUpEnv().env_name == "CartPoleSwingUp"
+
+
+def test_freeze_flags():
+    """test/test_core.py:17-23 of the reference."""
+    env = EmeiEnv(env_params=dict(freq_rate=1, time_step=0.02))
+    env.freeze()
+    assert env.frozen
+    with pytest.raises(AssertionError):
+        env.freeze()
+    env.unfreeze()
+    assert not env.frozen
+    with pytest.raises(AssertionError):
+        env.unfreeze()
+
+
+def test_abstract_cartpole_reset_raises():
+    """test_cartpole.py:4-11 of the reference."""
+    with pytest.raises(NotImplementedError):
+        emei_amd.BaseCartPoleEnv().reset()
+
+
+def test_transition_graph_closure(mujoco_golden):
+    env = emei_amd.BoundaryInvertedPendulumSwingUpEnv()
+    for rt in (1, 2, 3, 5):
+        assert np.array_equal(env.get_transition_graph(rt), mujoco_golden[f"ip_graph_repeat{rt}"])
+    with pytest.raises(AttributeError):  # CartPole defines no graph: None.copy() (core.py:143)
+        emei_amd.CartPoleSwingUpEnv().get_transition_graph()
+
+
+@pytest.mark.parametrize("name,cls", [("swingup", emei_amd.CartPoleSwingUpEnv), ("balancing", emei_amd.CartPoleBalancingEnv)])
+def test_host_init_states_match_reference(cartpole_golden, name, cls):
+    g = cartpole_golden
+    for seed in range(16):
+        env = cls()
+        env._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        assert np.array_equal(env.get_batch_init_state(1)[0], g[f"reset_{name}_seeds0_15"][seed])
+    # the fixture was drawn after reset(seed=7), which itself consumes one row (base_control.py:44-46)
+    env._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(7)))
+    env.get_batch_init_state(1)
+    assert np.array_equal(env.get_batch_init_obs(8), g[f"batchinitobs_{name}_seed7_B8"])
+
+
+def test_mujoco_init_noise_quirk(mujoco_golden):
+    """mujoco_env.py:243-244: for B = 1 one draw is added to every qpos entry, one to every qvel entry."""
+    g = mujoco_golden
+    for seed in range(8):
+        np.random.seed(seed)
+        pos, vel = emei_amd.BoundaryInvertedPendulumBalancingEnv().get_batch_init_state(1)
+        assert np.array_equal(pos[0], g["noise_ip_pos_seeds0_7"][seed]) and np.array_equal(vel[0], g["noise_ip_vel_seeds0_7"][seed])
+        np.random.seed(seed)
+        pos, vel = emei_amd.HalfCheetahRunningEnv().get_batch_init_state(1)
+        assert np.array_equal(pos[0], g["noise_cheetah_pos_seeds0_7"][seed]) and np.array_equal(vel[0], g["noise_cheetah_vel_seeds0_7"][seed])
+    pos, vel = emei_amd.BoundaryInvertedPendulumBalancingEnv().get_batch_init_state(64)
+    assert pos.shape == (64, 2) and vel.shape == (64, 2) and np.unique(pos).size == 128  # i.i.d. per coordinate
+
+
+def test_spaces_and_registry():
+    d = spaces.Discrete(2)
+    assert d.contains(0) and d.contains(np.asarray(1)) and not d.contains(2) and not d.contains(0.5) and not d.contains(np.asarray([1]))
+    b = spaces.Box(-3.0, 3.0, shape=(1,), dtype=np.float32)
+    assert b.contains(np.array([2.5], np.float32)) and not b.contains(np.array([3.5], np.float32)) and not b.contains(np.zeros(2))
+    assert emei_amd.spec("CartPoleSwingUp-v0")["max_episode_steps"] == 1000  # register_env.py:19-23
+    assert emei_amd.spec("CartPoleBalancing-v0")["max_episode_steps"] == 500  # register_env.py:14-18
+    env = emei_amd.make("BoundaryInvertedPendulumBalancing-v0", freq_rate=4)
+    assert env.max_episode_steps == 1000 and env.freq_rate == 4 and env.observation_space.shape == (4,)
+    assert emei_amd.make("HalfCheetahRunning-v0").dt == pytest.approx(0.008)
+    with pytest.raises(KeyError):
+        emei_amd.spec("Hopper-v0")
+    with pytest.raises(NotImplementedError):
+        emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator="rk4")
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """include/emei_hip.h is the contract: every EMEI_API function must be exported by the .so
+    (no compute call is made here)."""
+    hdr = open(os.path.join(ROOT, "include", "emei_hip.h")).read()
+    declared = set(re.findall(r"EMEI_API\s+[\w\s\*]+?\b(emei_\w+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.emei_abi_version() == _lib.ABI_VERSION
+    od, ad, sd = C.c_int(), C.c_int(), C.c_int()
+    assert lib.emei_env_dims(_lib.ENV_IDS["HalfCheetahRunning"], C.byref(od), C.byref(ad), C.byref(sd)) == 0
+    assert (od.value, ad.value, sd.value) == (18, 6, 18)
+    assert lib.emei_env_dims(99, None, None, None) == _lib.ERR_INVALID
+    # the struct layout of the binding is checked by the library itself
+    cfg = _lib.EmeiConfig(C.sizeof(_lib.EmeiConfig) - 8, 0, 16, 1, 0, 0.02, 0, 0, 0, 0, 0.0)
+    h = C.c_void_p()
+    assert lib.emei_create(C.byref(cfg), C.byref(h)) == _lib.ERR_INVALID
+    assert b"emei_config size" in lib.emei_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.ERR_INVALID)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if " T " in l}
+    assert {s for s in exported if s.startswith("emei_")} == declared  # nothing undeclared leaks out either
+
+
+def test_no_product_import_of_the_oracle():
+    """The product package must never reach into oracle/ (it is test infrastructure)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "emei_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libemei_oracle" not in txt, f
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.EmeiHipError):
+        emei_amd.CartPoleSwingUpEnv().reset(seed=0)

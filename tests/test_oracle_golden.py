@@ -1,0 +1,105 @@
+"""The CPU oracle against the golden vectors produced by the real reference (oracle/gen_golden.py).
+This is what pins the oracle: bit-exact for the first-party CartPole arithmetic."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import oracle as O
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr,dt", [(1, 0.02), (4, 0.02), (2, 0.01)])
+def test_cartpole_onestep_bit_exact(cartpole_golden, name, fr, dt):
+    g = cartpole_golden
+    tag = f"onestep_{name}_fr{fr}_dt{dt}"
+    ok = ~g[tag + "_raised"]  # rows where the reference itself raises (math.cos(inf)) have no answer
+    nxt, rew, term = O.cartpole_step(name, g[f"onestep_{name}_state"], g[f"onestep_{name}_action"], fr, dt)
+    assert _same(nxt[ok], g[tag + "_next"][ok])
+    assert np.array_equal(term[ok], g[tag + "_terminal"][ok])
+    assert rel_err(rew[ok], g[tag + "_reward"][ok], floor=1e-300) <= 4e-16  # numpy cos vs libm cos
+    # the NumPy restatement agrees with the C one
+    n2, r2, t2 = O.cartpole_step_numpy(name, g[f"onestep_{name}_state"], g[f"onestep_{name}_action"], fr, dt)
+    assert rel_err(n2[ok], nxt[ok], floor=1e-30) <= 1e-6 and np.array_equal(t2[ok], term[ok])
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr", [1, 4])
+@pytest.mark.parametrize("seed", range(4))
+def test_cartpole_trajectory_bit_exact(cartpole_golden, name, fr, seed):
+    """BASELINE configs[0]: 1 env, 1000 CPU steps, here for 16 (env, freq_rate, seed) combinations."""
+    g = cartpole_golden
+    tag = f"traj_{name}_fr{fr}_seed{seed}"
+    st, rew, term = O.cartpole_rollout(name, g[tag + "_states"][:1], g[tag + "_actions"][:, None], fr, 0.02)
+    assert _same(st[:, 0], g[tag + "_states"])
+    assert np.array_equal(term[:, 0], g[tag + "_terminal"])
+    assert rel_err(rew[:, 0], g[tag + "_reward"], floor=1e-300) <= 4e-16
+
+
+def test_baseline_md_first_rows(cartpole_golden):
+    """The values quoted in BASELINE.md / SURVEY.md 8c: reset(seed=0) then actions 0, 1, 1."""
+    s0 = O.cartpole_init_state_host("swingup", 0, 1)
+    assert np.allclose(s0[0], [0.01369617, -0.02302133, 3.09569001, -0.04834724], atol=5e-9)
+    st, rew, term = O.cartpole_rollout("swingup", s0, np.array([[0], [1], [1]]))
+    assert np.allclose(st[1, 0], [0.01323574, -0.21745584, 3.09472306, -0.32620114], atol=5e-9)
+    assert np.allclose(st[3, 0], [0.00845284, 0.17415616, 3.08781706, 0.28994059], atol=5e-9)
+    assert rew[0, 0] == pytest.approx(0.0005490891410523391, rel=1e-12) and not term.any()
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+def test_cartpole_reset_and_batch_functions(cartpole_golden, name):
+    g = cartpole_golden
+    for seed in range(16):
+        assert _same(O.cartpole_init_state_host(name, seed, 1)[0], g[f"reset_{name}_seeds0_15"][seed])
+    # drawn after reset(seed=7), which consumes the first row of the stream (base_control.py:44-46)
+    assert _same(O.cartpole_init_state_host(name, 7, 9)[1:], g[f"batchinit_{name}_seed7_B8"])
+    obs = g[f"batch_{name}_obs"]
+    assert np.array_equal(O.cartpole_terminal(name, obs)[:, None], g[f"batch_{name}_terminal"])
+    assert rel_err(O.cartpole_reward(name, obs)[:, None], g[f"batch_{name}_reward"], floor=1e-300) <= 4e-16
+
+
+@pytest.mark.parametrize("variant", ["rebound_balancing", "boundary_balancing", "rebound_swingup", "boundary_swingup"])
+def test_invpend_reward_terminal(mujoco_golden, variant):
+    g = mujoco_golden
+    obs = g["ip_obs"]
+    assert np.array_equal(O.ip_terminal(variant, obs)[:, None], g[f"ip_{variant}_terminal"])
+    assert rel_err(O.ip_reward(variant, obs)[:, None], g[f"ip_{variant}_reward"], floor=1e-300) <= 4e-16
+
+
+def test_invpend_wrap_and_euler_rule(mujoco_golden):
+    g = mujoco_golden
+    assert np.array_equal(O.ip_wrap(g["ip_wrap_in"][:, 1]), g["ip_wrap_out"][:, 1])
+    # forward-Euler position rule (mujoco_env.py:189-191) through one oracle substep: q' = q + dt*v_old
+    for dt in (0.02, 0.002):
+        qp, qv = g[f"euler_ip_dt{dt}_qpos"], g[f"euler_ip_dt{dt}_qvel"]
+        st = np.concatenate([qp * 0.1, qv], axis=1)  # keep x inside the rail so no limit force acts
+        nxt, _, _, _ = O.ip_step("boundary_swingup", st, np.zeros(len(st)), 1, dt)
+        assert rel_err(nxt[:, :2], st[:, :2] + dt * st[:, 2:], floor=1e-30) <= 1e-15
+
+
+def test_invpend_model_constants():
+    """inertia-from-geom of assets/inverted_pendulum.xml: capsule masses with density 1000."""
+    m = O.ip_model()
+    assert m.mc == pytest.approx(1000 * (np.pi * 0.01 * 0.2 + 4 / 3 * np.pi * 1e-3), rel=1e-14)  # 10.472 kg
+    assert m.mp == pytest.approx(5.0186, rel=1e-4)
+    assert m.r == pytest.approx(0.3, rel=1e-5) and 0 < m.phi0 < 2e-3
+    assert m.gear == 100 and (m.x_lo, m.x_hi) == (-2.0, 2.0) and m.g == 9.81
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10 (counter = (env lo, env hi, episode, block), key = seed)."""
+    assert [int(x) for x in O.philox(0, 0, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(x) for x in O.philox(2**64 - 1, 2**64 - 1, 2**32 - 1, 2**32 - 1)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert [int(x) for x in O.philox(0x299F31D0A4093822, 0x85A308D3243F6A88, 0x13198A2E, 0x03707344)] == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_device_reset_distribution():
+    s = np.stack([O.cartpole_init_f32("swingup", 3, e, 0) for e in range(4096)])
+    s[:, 2] -= np.float32(np.pi)
+    assert (np.abs(s) <= 0.05 + 1e-6).all() and abs(s.mean()) < 2e-3 and s.std() == pytest.approx(0.1 / 12**0.5, rel=0.05)
+    z = np.stack([O.ip_init_f32(3, e, 0, 1.0) for e in range(4096)])
+    assert abs(z.mean()) < 0.05 and z.std() == pytest.approx(1.0, rel=0.05)

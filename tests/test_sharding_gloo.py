@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercising the shard partition and the all-gather
+of the batched observation return (RCCL on GPUs)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_per_rank, q):
+    sys.path.insert(0, ROOT)
+    from emei_amd.sharding import allgather_obs, shard_bounds, synthetic_init_state
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_global = world * n_per_rank
+        lo, hi = shard_bounds(n_global, rank, world)
+        assert (lo, hi) == (rank * n_per_rank, (rank + 1) * n_per_rank)
+        # every rank draws the GLOBAL init array and keeps its slice: results independent of world size
+        full = synthetic_init_state("CartPoleSwingUp", n_global, 0, n_global, seed=0)
+        mine = synthetic_init_state("CartPoleSwingUp", n_global, lo, hi, seed=0)
+        assert np.array_equal(full[lo:hi], mine)
+        local = torch.as_tensor(mine, dtype=torch.float32)
+        for _ in range(3):  # repeated collectives, as in a stepping loop
+            gathered = allgather_obs(local)
+        ok = torch.equal(gathered, torch.as_tensor(full, dtype=torch.float32))
+        q.put((rank, bool(ok), tuple(gathered.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_allgather_obs_world2():
+    world, n = 2, 96
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(0, True, (world * n, 4)), (1, True, (world * n, 4))]
+
+
+def test_shard_bounds_cover_and_balance():
+    from emei_amd.sharding import shard_bounds
+
+    for n, w in ((1048576, 8), (65536, 1), (10, 3), (7, 8)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
