@@ -316,7 +316,7 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
         PendLaunch L;
         L.op = PEND_OP_REWARD_TERMINAL;
         L.env_id = env_id;
-        L.precision = EMEI_PRECISION_F32;
+        L.precision = EMEI_PRECISION_REF;  // float32 in/out, evaluated in float64
         L.obs_in = obs;
         L.reward_out = reward_out;
         L.n = n;
@@ -340,7 +340,7 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
         PendLaunch L;
         L.op = PEND_OP_REWARD_TERMINAL;
         L.env_id = env_id;
-        L.precision = EMEI_PRECISION_F32;
+        L.precision = EMEI_PRECISION_REF;
         L.obs_in = obs;
         L.done_out = terminal_out;
         L.n = n;

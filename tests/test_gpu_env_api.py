@@ -1,0 +1,101 @@
+"""The EmeiEnv-shaped Python surface driven the way the reference's own tests and callers drive it."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import emei_amd  # noqa: E402
+
+
+@pytest.mark.parametrize("name,cls", [("swingup", emei_amd.CartPoleSwingUpEnv), ("balancing", emei_amd.CartPoleBalancingEnv)])
+@pytest.mark.parametrize("fr", [1, 4])
+def test_single_env_reproduces_reference_trajectory(cartpole_golden, name, cls, fr):
+    """BASELINE configs[0] through the gym-style API: reset(seed) + 1000 x step(int)."""
+    g = cartpole_golden
+    tag = f"traj_{name}_fr{fr}_seed0"
+    env = cls(freq_rate=fr)
+    obs, info = env.reset(seed=0)
+    assert info == {} and obs.dtype == np.float64 and np.array_equal(obs, g[tag + "_states"][0])
+    T = 300
+    for t in range(T):
+        obs, reward, terminal, truncated, info = env.step(int(g[tag + "_actions"][t]))
+        assert isinstance(reward, np.float64) and isinstance(terminal, np.bool_) and truncated is False and info == {}
+        assert rel_err(obs, g[tag + "_states"][t + 1], floor=1e-30) <= 1e-9
+        assert abs(reward - g[tag + "_reward"][t]) <= 1e-6 and bool(terminal) == bool(g[tag + "_terminal"][t])
+
+
+def test_reference_behaviour_tests_cartpole():
+    """test_cartpole.py:14-35: both envs eventually return terminal=True under action_space.sample()."""
+    for cls in (emei_amd.CartPoleBalancingEnv, emei_amd.CartPoleSwingUpEnv):
+        env = cls()
+        obs, info = env.reset(seed=3)
+        env.action_space.seed(3)
+        for _ in range(5000):
+            obs, reward, terminal, truncated, info = env.step(env.action_space.sample())
+            if terminal:
+                break
+        assert terminal
+
+
+def test_step_before_reset_and_bad_action():
+    env = emei_amd.CartPoleSwingUpEnv()
+    with pytest.raises(AssertionError, match="Call reset before using step method"):
+        env.step(0)
+    env.reset(seed=0)
+    with pytest.raises(AssertionError, match="invalid"):
+        env.step(2)  # not in Discrete(2): base_control.py:65-66
+    with pytest.raises(AssertionError, match="invalid"):
+        env.step(0.5)
+
+
+def test_make_applies_time_limit():
+    env = emei_amd.make("CartPoleBalancing-v0", num_envs=64)
+    env.reset(seed=0)
+    acts = torch.randint(0, 2, (500, 64), device=env.engine.device, dtype=torch.uint8)
+    obs, rew, term, trunc = env.rollout(acts)
+    assert bool(trunc[-1].all()) and not bool(trunc[:-1].any())  # register_env.py:14-18: 500 steps
+
+
+def test_vectorised_env_and_batch_functions(cartpole_golden):
+    g = cartpole_golden
+    env = emei_amd.CartPoleSwingUpEnv(num_envs=128)
+    obs, _ = env.reset(seed=0)
+    want = np.random.default_rng(0).uniform(-0.05, 0.05, (128, 4))
+    want[:, 2] += np.pi
+    assert np.array_equal(obs.cpu().numpy(), want)  # same PCG64 stream as the reference's reset(seed=0)
+    o, r, term, trunc, info = env.step(torch.ones(128, dtype=torch.int64, device=obs.device))
+    assert o.shape == (128, 4) and r.shape == (128,) and term.dtype == torch.bool and not bool(trunc.any())
+    # numpy in -> numpy [B,1] out, like the reference; torch in -> torch out
+    ob = g["batch_swingup_obs"]
+    r_np, t_np = env.get_batch_reward(ob), env.get_batch_terminal(ob)
+    assert r_np.shape == (len(ob), 1) and r_np.dtype == np.float64 and t_np.dtype == np.bool_
+    near = np.abs(ob[:, 2]) < 15.0  # the ABI takes float32 observations: |theta| ~ 600 rad rows lose 3e-5 rad
+    assert rel_err(r_np[near], g["batch_swingup_reward"][near]) <= 1e-5
+    assert isinstance(env.get_batch_reward(torch.as_tensor(ob, device=obs.device)), torch.Tensor)
+    assert np.array_equal(emei_amd.CartPoleBalancingEnv().get_batch_reward(ob), np.ones((len(ob), 1)))
+    # get_batch_next_obs needs a frozen env (core.py:190-193) and leaves the env's own state alone
+    with pytest.raises(AssertionError):
+        env.get_batch_next_obs(ob, action=np.zeros(len(ob), np.int64))
+    before = env.engine.get_state().clone()
+    env.freeze()
+    nxt = env.get_batch_next_obs(g["onestep_swingup_state"][:64], action=g["onestep_swingup_action"][:64])
+    env.unfreeze()
+    assert torch.equal(env.engine.get_state(), before)
+    assert rel_err(nxt, g["onestep_swingup_fr1_dt0.02_next"][:64]) <= 1e-5
+
+
+def test_inverted_pendulum_env_api():
+    env = emei_amd.BoundaryInvertedPendulumBalancingEnv()
+    np.random.seed(0)
+    obs, _ = env.reset()
+    assert obs.shape == (4,) and abs(obs[0] - obs[1]) < 1e-15 and obs[2] == obs[3] and abs(obs[0]) < 0.05  # B=1 noise quirk (theta went through the wrap)
+    for _ in range(2000):
+        obs, reward, terminal, truncated, info = env.step(env.action_space.sample())
+        if terminal:
+            break
+    assert terminal and reward == 1.0
+    with pytest.raises(ValueError):
+        env.step(np.zeros(2, np.float32))

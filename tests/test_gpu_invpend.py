@@ -1,0 +1,151 @@
+"""InvertedPendulum kernels against the oracle (float64 restatement of the same MuJoCo 2-DoF model +
+emei's forward-Euler override) and against the golden reward/terminal vectors of the reference.
+Parity with libmujoco itself is unpinned (no MuJoCo in the image): see DESIGN.md."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+RTOL = 1e-5
+VARIANTS = {
+    "rebound_balancing": "ReboundInvertedPendulumBalancing",
+    "boundary_balancing": "BoundaryInvertedPendulumBalancing",
+    "rebound_swingup": "ReboundInvertedPendulumSwingUp",
+    "boundary_swingup": "BoundaryInvertedPendulumSwingUp",
+}
+
+
+def _engine(*a, **k):
+    from emei_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+def _states(rng, n):
+    s = np.empty((n, 4))
+    s[:, 0] = rng.uniform(-2.3, 2.3, n)  # beyond the +-2 rail on purpose: limit force engaged
+    s[:, 1] = rng.uniform(-12, 12, n)
+    s[:, 2] = rng.normal(0, 2, n)
+    s[:, 3] = rng.normal(0, 5, n)
+    s[: n // 4] = rng.standard_normal((n // 4, 4)) * 5e-3
+    return s
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("fr,dt", [(1, 0.02), (4, 0.02), (4, 0.002)])
+@pytest.mark.parametrize("precision", ["ref", "f32"])
+def test_onestep_vs_oracle(variant, fr, dt, precision):
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(42)
+    n = 2048
+    s0 = _states(rng, n)
+    act = rng.uniform(-3.5, 3.5, n).astype(np.float32)  # beyond ctrlrange: clipping exercised
+    eng = _engine(VARIANTS[variant], n, freq_rate=fr, real_time_scale=dt, precision=precision)
+    eng.set_state(s0)
+    obs, rew, done = eng.step(torch.as_tensor(act, device=eng.device))
+    o_st, o_obs, o_rew, o_term = O.ip_step(variant, s0, act.astype(np.float64), fr, dt)
+    tol = RTOL if precision == "ref" else 2e-4
+    assert rel_err(obs.cpu().numpy(), o_obs) <= tol
+    assert rel_err(rew.cpu().numpy(), o_rew) <= tol
+    if precision == "ref":
+        assert rel_err(eng.get_state().cpu().numpy(), o_st, floor=1e-30) <= 1e-9
+        assert rel_err(eng.get_obs().cpu().numpy(), o_obs, floor=1e-30) <= 1e-9
+        # masks bit-exact away from the thresholds (cos theta vs 0.9 / 0, x vs +-2)
+        y = np.cos(o_obs[:, 1])
+        clear = (np.abs(y - 0.9) > 1e-9) & (np.abs(y) > 1e-9) & (np.abs(np.abs(o_obs[:, 0]) - 2) > 1e-9)
+        assert np.array_equal((done.cpu().numpy() & 1)[clear].astype(bool), o_term[clear])
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_trajectory_vs_oracle(variant):
+    """Open loop in segments: the float64 MuJoCo-style dynamics (stiff rail constraint, explicit Euler,
+    no float32 rounding of the derivative to absorb last-bit differences) amplify 1e-16 by many orders
+    over hundreds of substeps, so the oracle is re-synchronised to the device state every 25 steps
+    (100 substeps) and each segment must agree to 1e-5."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(7)
+    n, T, fr, seg = 64, 200, 4, 25
+    s0 = rng.standard_normal((n, 4)) * 5e-3
+    acts = rng.uniform(-3, 3, (T, n)).astype(np.float32)
+    eng = _engine(VARIANTS[variant], n, freq_rate=fr, precision="ref")
+    eng.set_state(s0)
+    for t0 in range(0, T, seg):
+        st = eng.get_state().cpu().numpy()
+        obs, rew, done = eng.rollout(torch.as_tensor(acts[t0 : t0 + seg], device=eng.device))
+        o_obs = np.empty((seg, n, 4))
+        o_rew = np.empty((seg, n))
+        for t in range(seg):
+            st, o_obs[t], o_rew[t], _ = O.ip_step(variant, st, acts[t0 + t].astype(np.float64), fr, 0.02)
+        got = obs.cpu().numpy().astype(np.float64)
+        dth = np.angle(np.exp(1j * (got[..., 1] - o_obs[..., 1])))  # theta wraps at +-pi: compare on the circle
+        got[..., 1] = o_obs[..., 1] + dth
+        assert rel_err(got, o_obs) <= RTOL, t0
+        assert rel_err(rew.cpu().numpy(), o_rew) <= RTOL, t0
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_reward_terminal_vs_golden(mujoco_golden, variant):
+    from emei_amd import engine as E
+
+    g = mujoco_golden
+    obs = g["ip_obs"]
+    o32 = torch.as_tensor(obs, dtype=torch.float32, device="cuda")
+    rew = E.batch_reward(VARIANTS[variant], o32).cpu().numpy()
+    term = E.batch_terminal(VARIANTS[variant], o32).cpu().numpy()
+    assert rel_err(rew, g[f"ip_{variant}_reward"][:, 0]) <= RTOL
+    y = np.cos(obs[:, 1])
+    clear = (np.abs(y - 0.9) > 1e-6) & (np.abs(y) > 1e-6) & (np.abs(np.abs(obs[:, 0]) - 2) > 1e-6)
+    assert np.array_equal(term[clear], g[f"ip_{variant}_terminal"][clear, 0])
+
+
+def test_behaviour_like_reference_tests():
+    """test/test_envs/test_mujoco/test_inverted_pendulum.py:14-62 of the reference, vectorised:
+    under random actions Rebound/Boundary Balancing and Boundary SwingUp terminate eventually,
+    Rebound SwingUp must NOT terminate within 100 steps."""
+    n, T = 256, 1000
+    acts = (torch.rand((T, n), device="cuda") * 6 - 3).float()
+    for variant, must in (("rebound_balancing", True), ("boundary_balancing", True), ("boundary_swingup", True)):
+        eng = _engine(VARIANTS[variant], n, freq_rate=1, init_noise=5e-3, seed=1)
+        eng.reset(1)
+        _, _, done = eng.rollout(acts)
+        assert bool(((done & 1) != 0).any(dim=0).all()) == must, variant
+    eng = _engine(VARIANTS["rebound_swingup"], n, freq_rate=1, init_noise=5e-3, seed=1)
+    eng.reset(1)
+    _, _, done = eng.rollout(acts[:100].contiguous())
+    assert not bool((done & 1).any())
+    # the rail holds the cart: |x| stays close to the +-2 range under constant full push
+    eng = _engine(VARIANTS["rebound_swingup"], n, freq_rate=1, init_noise=5e-3, seed=1)
+    eng.reset(1)
+    obs, _, _ = eng.rollout(torch.full((400, n), 3.0, device="cuda"))
+    assert float(obs[..., 0].abs().max()) < 2.5 and float(obs[-1, :, 0].min()) > 1.5
+
+
+def test_device_reset_matches_oracle_spec():
+    from oracle import oracle as O
+
+    eng = _engine(VARIANTS["boundary_swingup"], 512, init_noise=5e-3, seed=21, env_index_offset=77)
+    eng.reset(21)
+    got = eng.get_state().cpu().numpy()
+    want = np.stack([O.ip_init_f32(21, 77 + i, 0, 5e-3) for i in range(512)]).astype(np.float64)
+    assert np.abs(got - want).max() <= 5e-9  # Box-Muller through different libm's: a few float32 ulp of 5e-3
+
+
+def test_full_size_config3_properties():
+    """BASELINE configs[2]: 262 144 envs, freq_ratio 4 — rollout == chunked rollouts; obs angle in [-pi, pi)."""
+    N, T = 262144, 32
+    acts = (torch.rand((T, N), device="cuda") * 6 - 3).float()
+    a = _engine(VARIANTS["boundary_swingup"], N, freq_rate=4, init_noise=5e-3, max_episode_steps=1000, seed=2)
+    a.reset(2)
+    obs, rew, done = a.rollout(acts, auto_reset=True)
+    b = _engine(VARIANTS["boundary_swingup"], N, freq_rate=4, init_noise=5e-3, max_episode_steps=1000, seed=2)
+    b.reset(2)
+    p = [b.rollout(acts[k : k + 16].contiguous(), auto_reset=True) for k in (0, 16)]
+    assert torch.equal(torch.cat([p[0][0], p[1][0]]), obs) and torch.equal(torch.cat([p[0][2], p[1][2]]), done)
+    th = obs[..., 1]
+    assert float(th.min()) >= -np.pi - 1e-6 and float(th.max()) < np.pi + 1e-6
+    assert float(rew.min()) >= 0 and float(rew.max()) <= 1 and bool(torch.isfinite(obs).all())
