@@ -123,9 +123,12 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream)
     for _ in range(a.steps):
-        sr.run_pass(record=True)
+        sr.run_pass()
+    ev1.record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -136,16 +139,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    kernel_ms = sr.mean_kernel_ms()  # HIP events on the launch stream, this rank
+    # average launch duration of the dominant kernel over the timed region: at one GPU a pass is
+    # exactly one rollout launch, so the event pair around the K passes / K is the kernel's duration
+    # (plus the ~1.5 us dependent-launch gap); with several ranks the all-gather sits between launches
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps if world == 1 else sr.timed_launches_ms(a.steps)
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / el
     bpes = algorithmic_bytes_per_env_step(sr.obs_dim, sr.action_bytes)
     achieved = bpes * N * T / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic.json, written from
+    # tools/collect_profiles.sh output with the gfx950 FETCH_SIZE correction); only valid for the
+    # default shape it was collected on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and N == w["n"] and T == w["horizon"] and a.precision == "ref":
         try:
-            traffic = json.load(open(tpath)).get(a.workload)
+            traffic = json.load(open(tpath)).get(a.workload, {}).get("bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -159,7 +168,8 @@ def main():
                    "obs_allgather": "final obs of each pass over RCCL" if world > 1 else "n/a (1 GPU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": sr.kernel_name,
-                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes},
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes,
+                     "algorithmic_bytes_per_launch": bpes * N * T},
     }
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()

@@ -119,6 +119,17 @@ class ShardedRollout:
         ts = [a.elapsed_time(b) for a, b in self._events]
         return float(np.mean(ts)) if ts else float("nan")
 
+    def timed_launches_ms(self, k):
+        """Mean duration of k back-to-back rollout launches bracketed by ONE pair of HIP events on the
+        launch stream (no per-launch marker packets inside the timed span)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            self.engine.rollout(self.actions, auto_reset=True, out=self.out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
     def time_per_step_api(self, n_steps=200):
         """One launch per env-step (emei_step), the gym-style API: launch-bound by construction."""
         import time
