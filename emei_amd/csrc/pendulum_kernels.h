@@ -233,27 +233,32 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
         EMEI_LOAD_TILE(t0 + kStage, buf ^ 1)  // next tile: in flight under the 16 steps below
         const ActT* act_l = (const ActT*)&act_s[wv][buf][0];
         ActT act_cur = act_l[lane];
+        // 16 steps = 4 groups (a real loop) x 4 unrolled steps (one reward flush period).  Unrolling all
+        // 16 put ~70 KB of code (each step carries its out-of-line reset and trig-repair blocks) in
+        // the loop, more than the 64 KB instruction cache two CUs share.
+#pragma unroll 1
+        for (int g = 0; g < kStage / 4; ++g) {
 #pragma unroll
-        for (int j = 0; j < kStage; ++j) {
-            // the next step's action leaves LDS while this step computes
-            const ActT act_now = act_cur;
-            if (j + 1 < kStage) act_cur = act_l[(j + 1) * kWave + lane];
-            R o[4], rew;
-            advance(act_now, o, rew);
-            (a.obs_out + (int64_t)(t0 + j) * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-            if (j == 0) {
-                if (t0 > 0) {  // rows staged by the last steps of the previous tile
-                    store_rew_rows(t0 - 4, rew_pend);
-                    store_done_rows(t0 - kStage, done_pend);
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * g + q;
+                // the next step's action leaves LDS while this step computes
+                const ActT act_now = act_cur;
+                act_cur = act_l[min(j + 1, kStage - 1) * kWave + lane];
+                R o[4], rew;
+                advance(act_now, o, rew);
+                (a.obs_out + (int64_t)(t0 + j) * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+                if (q == 0) {  // rows staged during the previous group: their LDS read has landed
+                    if (t0 + j > 0) store_rew_rows(t0 + j - 4, rew_pend);
+                    if (g == 0 && t0 > 0) store_done_rows(t0 - kStage, done_pend);
                 }
-            } else if ((j & 3) == 0) {
-                store_rew_rows(t0 + j - 4, rew_pend);
+                rew_s[wv][q][lane] = (float)rew;
+                done_s[wv][j][lane] = (uint8_t)done;
+                if (q == 3) {
+                    rew_pend = ((const float4*)&rew_s[wv][0][0])[lane];                             // 4 rows x 256 B
+                    if (g == kStage / 4 - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];  // 16 rows x 64 B
+                }
+                maybe_reset();
             }
-            rew_s[wv][j & 3][lane] = (float)rew;
-            done_s[wv][j][lane] = (uint8_t)done;
-            if ((j & 3) == 3) rew_pend = ((const float4*)&rew_s[wv][0][0])[lane];           // 4 rows x 256 B
-            if (j == kStage - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];       // 16 rows x 64 B
-            maybe_reset();
         }
         // retire the tile: it is older than this tile's stores (16 obs + >= 3 reward flushes), so
         // leaving the 19 youngest operations in flight still covers every LDS-DMA load
