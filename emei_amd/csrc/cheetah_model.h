@@ -1,0 +1,326 @@
+// cheetah_model.h — device arithmetic of the HalfCheetah-style planar body (9 DoF, 7 links).
+//
+// Model: emei/envs/mujoco/assets/half_cheetah.xml stepped the way emei steps it
+// (emei/envs/mujoco/mujoco_env.py:86-109,169-195): MuJoCo's Euler substep (implicit joint damping)
+// with emei's forward-Euler position override.  Parity with libmujoco is UNPINNED (no MuJoCo in
+// the image): the CPU oracle (oracle/cheetah_oracle.c) restates the same model with MuJoCo's own
+// algorithms (recursive Newton-Euler in joint coordinates, dense factorisation); this file is an
+// independent formulation of the same equations, chosen for the GPU:
+//
+//   * ABSOLUTE link angles phi_b as velocity coordinates u = (xdot, zdot, Omega_0..Omega_6).  In
+//     these coordinates the inertia matrix of a planar tree is
+//         M[phi_i, phi_i] = const,   M[phi_i, phi_j] = (R_i d_ij) . S_j   (i ancestor of j),
+//         M[x|z, phi_j]   = perp(S_j),   S_j = R(phi_j) s_j,
+//     with one constant "mass-moment" vector s_j per link, and the velocity-product forces are
+//         -sum_j Omega_j^2 (...) of the same rotated vectors: no recursion, 7 sincos per substep.
+//   * joint springs/dampers/armature/actuators/limits act on theta_k = phi_k - phi_parent(k): a
+//     torque tau_k enters as +tau_k on phi_k and -tau_k on phi_parent(k).
+//   * elimination order (leaves first: bfoot, bshin, bthigh, ffoot, fshin, fthigh, torso, x, z)
+//     makes the LDL^T factorisation fill-free; the zero blocks between the two legs are
+//     compile-time zeros of the fully unrolled loops.
+//   * constraints (6 joint limits, 16 capsule-end/floor contact points with friction) follow the
+//     oracle exactly: one Gauss-Seidel sweep in the same fixed order.
+#pragma once
+#include "emei_device.h"
+
+namespace emei {
+namespace cheetah {
+
+constexpr int NV = 9;
+// permuted index of each velocity coordinate
+enum { P_BFOOT = 0, P_BSHIN = 1, P_BTHIGH = 2, P_FFOOT = 3, P_FSHIN = 4, P_FTHIGH = 5, P_TORSO = 6, P_X = 7, P_Z = 8 };
+
+// structural non-zero of the (filled) lower triangle: same leg chain, or a row of torso/x/z
+__host__ __device__ constexpr bool nz(int i, int j) { return i >= 6 || (i / 3) == (j / 3); }
+
+// Model constants (computed on the host in double by cheetah.hip:make_model, passed by value).
+struct Model {
+    // mass-moment vector s_j (body frame) and constant diagonal inertia per link, permuted link order 0..6
+    double sx[7], sz[7], diag[7];
+    // link vectors to the child joint (body frame): torso->bthigh, torso->fthigh, bthigh->bshin,
+    // bshin->bfoot, fthigh->fshin, fshin->ffoot
+    double d_tb[2], d_tf[2], d_bt_bs[2], d_bs_bf[2], d_ft_fs[2], d_fs_ff[2];
+    double mtot, gravity, z0;                     // total mass, g, torso height at qpos0 (0.7)
+    double stiff[6], damp[6], arm[6], lo[6], hi[6], gear[6];  // joint order bthigh,bshin,bfoot,fthigh,fshin,ffoot
+    double geom_end[16][2];                       // capsule end-sphere centres, body frame; geom order torso,head,6 legs
+    double radius, friction;
+    double cK, cB, c_dmin, c_dmax, c_width;       // contact solref (refsafe'd for dt) / solimp
+    double lK, lB, l_dmin, l_dmax, l_width;       // joint-limit solref / solimp
+    double dt;
+    float init_sigma;
+};
+
+template <typename R>
+struct V2 {
+    R x, z;
+};
+template <typename R>
+__device__ __forceinline__ V2<R> rot(R c, R s, R ax, R az) {  // rotation about +y: x' = x c + z s, z' = -x s + z c
+    return V2<R>{fma_r(az, s, ax * c), fma_r(az, c, -(ax * s))};
+}
+template <typename R>
+__device__ __forceinline__ R dot(V2<R> a, V2<R> b) { return fma_r(a.x, b.x, a.z * b.z); }
+// a . perp(b), perp(b) = (b.z, -b.x)
+template <typename R>
+__device__ __forceinline__ R dotperp(V2<R> a, V2<R> b) { return fma_r(a.x, b.z, -(a.z * b.x)); }
+
+template <typename R>
+__device__ __forceinline__ R impedance(R dist, R dmin, R dmax, R width) {
+    R x = fabs(dist) / width;
+    R y = x >= R(1) ? R(1) : (x <= R(0.5) ? R(2) * x * x : R(1) - R(2) * (R(1) - x) * (R(1) - x));
+    R d = dmin + y * (dmax - dmin);
+    return d < R(1e-4) ? R(1e-4) : (d > R(0.9999) ? R(0.9999) : d);
+}
+
+// Sparse LDL^T in the permuted order.  L is stored in the strict lower triangle of A, 1/D in invd.
+template <typename R>
+__device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        invd[j] = rcp_r(A[j][j]);
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) {
+            if (!nz(i, j)) continue;
+            const R l = A[i][j] * invd[j];
+            // A[i][k] -= l * A[k][j] for j < k <= i (right-looking update with the unscaled column)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k)
+                if (nz(k, j) && nz(i, k)) A[i][k] = fma_r(-l, A[k][j], A[i][k]);
+        }
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i)
+            if (nz(i, j)) A[i][j] *= invd[j];
+    }
+}
+template <typename R>
+__device__ __forceinline__ void ldl_solve(const R (&A)[NV][NV], const R (&invd)[NV], R (&x)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i)
+            if (nz(i, j)) x[i] = fma_r(-A[i][j], x[j], x[i]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) x[j] *= invd[j];
+#pragma unroll
+    for (int j = NV - 1; j >= 0; --j)
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i)
+            if (nz(i, j)) x[j] = fma_r(-A[i][j], x[i], x[j]);
+}
+
+// q, v in the reference's order (rootx, rootz, rooty, bthigh, bshin, bfoot, fthigh, fshin, ffoot).
+template <typename R>
+__device__ __forceinline__ void substep(R (&q)[NV], R (&v)[NV], const R (&ctrl)[6], const Model& m) {
+    // ---- absolute angles / rates, permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso
+    R phi[7], om[7];
+    phi[6] = q[2], om[6] = v[2];
+    phi[2] = phi[6] + q[3], om[2] = om[6] + v[3];
+    phi[1] = phi[2] + q[4], om[1] = om[2] + v[4];
+    phi[0] = phi[1] + q[5], om[0] = om[1] + v[5];
+    phi[5] = phi[6] + q[6], om[5] = om[6] + v[6];
+    phi[4] = phi[5] + q[7], om[4] = om[5] + v[7];
+    phi[3] = phi[4] + q[8], om[3] = om[4] + v[8];
+    R cs[7], sn[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) sincos_r(phi[b], sn[b], cs[b]);
+    V2<R> S[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) S[b] = rot(cs[b], sn[b], (R)m.sx[b], (R)m.sz[b]);
+    // rotated link vectors
+    const V2<R> Dtb = rot(cs[6], sn[6], (R)m.d_tb[0], (R)m.d_tb[1]);          // torso -> bthigh joint
+    const V2<R> Dtf = rot(cs[6], sn[6], (R)m.d_tf[0], (R)m.d_tf[1]);          // torso -> fthigh joint
+    const V2<R> Dbt = rot(cs[2], sn[2], (R)m.d_bt_bs[0], (R)m.d_bt_bs[1]);    // bthigh -> bshin joint
+    const V2<R> Dbs = rot(cs[1], sn[1], (R)m.d_bs_bf[0], (R)m.d_bs_bf[1]);    // bshin -> bfoot joint
+    const V2<R> Dft = rot(cs[5], sn[5], (R)m.d_ft_fs[0], (R)m.d_ft_fs[1]);    // fthigh -> fshin joint
+    const V2<R> Dfs = rot(cs[4], sn[4], (R)m.d_fs_ff[0], (R)m.d_fs_ff[1]);    // fshin -> ffoot joint
+
+    // ---- inertia matrix (lower triangle, permuted) and generalized forces in absolute coordinates
+    R A[NV][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) A[i][j] = R(0);
+#pragma unroll
+    for (int b = 0; b < 7; ++b) A[b][b] = (R)m.diag[b];
+    A[P_X][P_X] = (R)m.mtot, A[P_Z][P_Z] = (R)m.mtot;
+    // angle-angle couplings along each chain: (ancestor link vector towards the descendant) . S_descendant
+    A[P_BSHIN][P_BFOOT] = dot(Dbs, S[0]);
+    A[P_BTHIGH][P_BFOOT] = dot(Dbt, S[0]);
+    A[P_BTHIGH][P_BSHIN] = dot(Dbt, S[1]);
+    A[P_TORSO][P_BFOOT] = dot(Dtb, S[0]);
+    A[P_TORSO][P_BSHIN] = dot(Dtb, S[1]);
+    A[P_TORSO][P_BTHIGH] = dot(Dtb, S[2]);
+    A[P_FSHIN][P_FFOOT] = dot(Dfs, S[3]);
+    A[P_FTHIGH][P_FFOOT] = dot(Dft, S[3]);
+    A[P_FTHIGH][P_FSHIN] = dot(Dft, S[4]);
+    A[P_TORSO][P_FFOOT] = dot(Dtf, S[3]);
+    A[P_TORSO][P_FSHIN] = dot(Dtf, S[4]);
+    A[P_TORSO][P_FTHIGH] = dot(Dtf, S[5]);
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {  // translation-angle: perp(S_b) = (S.z, -S.x)
+        A[P_X][b] = S[b].z;
+        A[P_Z][b] = -S[b].x;
+    }
+    // velocity-product (centripetal) and gravity forces, moved to the right-hand side
+    R f[NV];
+    R w2[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) w2[b] = om[b] * om[b];
+    {
+        R fx = R(0), fz = R(0);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) fx = fma_r(w2[b], S[b].x, fx), fz = fma_r(w2[b], S[b].z, fz);
+        f[P_X] = fx;
+        f[P_Z] = fz - (R)m.mtot * (R)m.gravity;
+    }
+    // Q_phi_i = g S_i.x + sum_{j != i, same chain} Omega_j^2 * (l_bj . perp(l_bi) summed over bodies)
+    //   i ancestor of j:  S_j . perp(D_i->j);   j ancestor of i:  D_j->i . perp(S_i)
+    const R g = (R)m.gravity;
+    f[P_BFOOT] = fma_r(g, S[0].x, w2[1] * dotperp(Dbs, S[0]) + w2[2] * dotperp(Dbt, S[0]) + w2[6] * dotperp(Dtb, S[0]));
+    f[P_BSHIN] = fma_r(g, S[1].x, w2[0] * dotperp(S[0], Dbs) + w2[2] * dotperp(Dbt, S[1]) + w2[6] * dotperp(Dtb, S[1]));
+    f[P_BTHIGH] = fma_r(g, S[2].x, w2[0] * dotperp(S[0], Dbt) + w2[1] * dotperp(S[1], Dbt) + w2[6] * dotperp(Dtb, S[2]));
+    f[P_FFOOT] = fma_r(g, S[3].x, w2[4] * dotperp(Dfs, S[3]) + w2[5] * dotperp(Dft, S[3]) + w2[6] * dotperp(Dtf, S[3]));
+    f[P_FSHIN] = fma_r(g, S[4].x, w2[3] * dotperp(S[3], Dfs) + w2[5] * dotperp(Dft, S[4]) + w2[6] * dotperp(Dtf, S[4]));
+    f[P_FTHIGH] = fma_r(g, S[5].x, w2[3] * dotperp(S[3], Dft) + w2[4] * dotperp(S[4], Dft) + w2[6] * dotperp(Dtf, S[5]));
+    f[P_TORSO] = fma_r(g, S[6].x,
+                       w2[0] * dotperp(S[0], Dtb) + w2[1] * dotperp(S[1], Dtb) + w2[2] * dotperp(S[2], Dtb) +
+                           w2[3] * dotperp(S[3], Dtf) + w2[4] * dotperp(S[4], Dtf) + w2[5] * dotperp(S[5], Dtf));
+
+    // ---- joints: child link / parent link (permuted) for joints bthigh,bshin,bfoot,fthigh,fshin,ffoot
+    constexpr int jc[6] = {P_BTHIGH, P_BSHIN, P_BFOOT, P_FTHIGH, P_FSHIN, P_FFOOT};
+    constexpr int jp[6] = {P_TORSO, P_BTHIGH, P_BSHIN, P_TORSO, P_FTHIGH, P_FSHIN};
+    const R dt = (R)m.dt;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);   // ctrlrange +-1
+        const R tau = (R)m.gear[k] * c - (R)m.stiff[k] * q[3 + k] - (R)m.damp[k] * v[3 + k];
+        f[jc[k]] += tau;
+        f[jp[k]] -= tau;
+        const R e = (R)m.arm[k] + dt * (R)m.damp[k];  // armature + implicit damping: M + h D on theta_k
+        A[jc[k]][jc[k]] += e;
+        A[jp[k]][jp[k]] += e;
+        // the (child,parent) entry lives in the lower triangle at [max][min]
+        const int hi_ = jc[k] > jp[k] ? jc[k] : jp[k], lo_ = jc[k] > jp[k] ? jp[k] : jc[k];
+        A[hi_][lo_] -= e;
+    }
+
+    R invd[NV];
+    ldl_factor(A, invd);
+    R acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = f[i];
+    ldl_solve(A, invd, acc);
+
+    // ---- soft constraints, one Gauss-Seidel sweep (oracle/cheetah_oracle.c order) -----------------
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // joint limits on theta_k
+        const R th = q[3 + k];
+        R dist = R(0), J = R(0);
+        if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
+        else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
+        if (J != R(0)) {
+            R w[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[i] = R(0);
+            w[jc[k]] = J, w[jp[k]] = -J;
+            ldl_solve(A, invd, w);
+            const R Aii = J * (w[jc[k]] - w[jp[k]]);
+            const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
+            const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+            const R Rr = (R(1) - imp) / imp * Aii;
+            const R force = (aref - J * (acc[jc[k]] - acc[jp[k]])) / (Aii + Rr);
+            if (force > R(0)) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[i] = fma_r(w[i], force, acc[i]);
+            }
+        }
+    }
+    // body origins (world) for the contact points
+    const V2<R> o_t = {q[0], (R)m.z0 + q[1]};
+    const V2<R> o_bt = {o_t.x + Dtb.x, o_t.z + Dtb.z}, o_bs = {o_bt.x + Dbt.x, o_bt.z + Dbt.z},
+                o_bf = {o_bs.x + Dbs.x, o_bs.z + Dbs.z};
+    const V2<R> o_ft = {o_t.x + Dtf.x, o_t.z + Dtf.z}, o_fs = {o_ft.x + Dft.x, o_ft.z + Dft.z},
+                o_ff = {o_fs.x + Dfs.x, o_fs.z + Dfs.z};
+    // velocities in absolute coordinates (permuted): u = (Omega_links..., xdot, zdot)
+    R u[NV];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) u[b] = om[b];
+    u[P_X] = v[0], u[P_Z] = v[1];
+
+    // one capsule end sphere of a body against the floor: `LNK` = permuted link of the body, `ORG` its
+    // origin, CH0..CH2 = (link, rotated vector) of the ancestors on its chain (compile-time list)
+    auto contact = [&](int pt, int lnk, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
+                       __attribute__((always_inline)) {
+        const V2<R> e = rot(cs[lnk], sn[lnk], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
+        const R sz_ = org.z + e.z;
+        const R dist = sz_ - (R)m.radius;
+        if (dist < R(0)) {
+            // contact point midway between the surfaces: p = (s.x, dist/2); offset from the body origin
+            const V2<R> r = {e.x, R(0.5) * dist - org.z};
+            R Jx[NV], Jz[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+            Jx[P_X] = R(1), Jz[P_Z] = R(1);
+            // d p / d phi_j = perp(vector from link j's contribution): own link uses r, ancestors their link vector
+            Jx[lnk] = r.z, Jz[lnk] = -r.x;
+            // an ancestor link a contributes its rotated link vector (the part of the chain it carries)
+            if (a1 >= 0) Jx[a1] = v1.z, Jz[a1] = -v1.x;
+            if (a2 >= 0) Jx[a2] = v2.z, Jz[a2] = -v2.x;
+            if (a3 >= 0) Jx[a3] = v3.z, Jz[a3] = -v3.x;
+            R wx[NV], wz[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) wx[i] = Jx[i], wz[i] = Jz[i];
+            ldl_solve(A, invd, wx);
+            ldl_solve(A, invd, wz);
+            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0), vn = R(0), vt = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                Ann = fma_r(Jz[i], wz[i], Ann), Att = fma_r(Jx[i], wx[i], Att), Atn = fma_r(Jx[i], wz[i], Atn);
+                an = fma_r(Jz[i], acc[i], an), at = fma_r(Jx[i], acc[i], at);
+                vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+            }
+            const R imp = impedance(dist, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
+            const R k1 = (R(1) - imp) / imp;
+            const R fn = (-(R)m.cB * vn - (R)m.cK * imp * dist - an) / (Ann + k1 * Ann);
+            if (fn > R(0)) {
+                R ft = (-(R)m.cB * vt - at - Atn * fn) / (Att + k1 * Att);
+                const R lim = (R)m.friction * fn;
+                ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[i] = fma_r(wz[i], fn, fma_r(wx[i], ft, acc[i]));
+            }
+        }
+    };
+    const V2<R> none = {R(0), R(0)};
+    // geom order: torso(0,1) head(2,3) bthigh(4,5) bshin(6,7) bfoot(8,9) fthigh(10,11) fshin(12,13) ffoot(14,15)
+    contact(0, P_TORSO, o_t, -1, none, -1, none, -1, none);
+    contact(1, P_TORSO, o_t, -1, none, -1, none, -1, none);
+    contact(2, P_TORSO, o_t, -1, none, -1, none, -1, none);
+    contact(3, P_TORSO, o_t, -1, none, -1, none, -1, none);
+    contact(4, P_BTHIGH, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+    contact(5, P_BTHIGH, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+    contact(6, P_BSHIN, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+    contact(7, P_BSHIN, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+    contact(8, P_BFOOT, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+    contact(9, P_BFOOT, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+    contact(10, P_FTHIGH, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+    contact(11, P_FTHIGH, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+    contact(12, P_FSHIN, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+    contact(13, P_FSHIN, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+    contact(14, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+    contact(15, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+
+    // ---- back to joint coordinates and integrate: q from the OLD velocity (emei), v from MuJoCo's Euler
+    R qacc[NV];
+    qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[P_TORSO];
+    qacc[3] = acc[P_BTHIGH] - acc[P_TORSO], qacc[4] = acc[P_BSHIN] - acc[P_BTHIGH], qacc[5] = acc[P_BFOOT] - acc[P_BSHIN];
+    qacc[6] = acc[P_FTHIGH] - acc[P_TORSO], qacc[7] = acc[P_FSHIN] - acc[P_FTHIGH], qacc[8] = acc[P_FFOOT] - acc[P_FSHIN];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        q[i] = fma_r(dt, v[i], q[i]);
+        v[i] = fma_r(dt, qacc[i], v[i]);
+    }
+}
+
+}  // namespace cheetah
+}  // namespace emei

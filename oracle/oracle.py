@@ -20,8 +20,8 @@ IP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup
 
 def build(force=False):
     """Compile the oracle with gcc (no GPU needed)."""
-    src = os.path.join(_HERE, "emei_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("emei_oracle.c", "cheetah_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
 
@@ -197,3 +197,44 @@ def ip_wrap(theta):
     out = np.empty_like(th)
     lib().emei_oracle_ip_wrap(C.c_int64(len(th)), _p(th, C.c_double), _p(out, C.c_double))
     return out
+
+
+# --------------------------------------------------------------------------- HalfCheetah-style body (C)
+def cheetah_step(state, action, freq_rate=4, dt=0.002):
+    """state [n,18] = (qpos, qvel) float64 (copied), action [n,6] -> (next_state, reward, terminal)."""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 18)
+    n = st.shape[0]
+    act = np.ascontiguousarray(action, dtype=np.float64).reshape(n, 6)
+    rew = np.empty(n)
+    term = np.empty(n, np.uint8)
+    lib().cheetah_oracle_step(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
+                              _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    return st, rew, term.astype(bool)
+
+
+def cheetah_reward(obs, pre_obs, act, dt_env):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 18)
+    pre = np.ascontiguousarray(pre_obs, np.float64).reshape(-1, 18)
+    a = np.ascontiguousarray(act, np.float64).reshape(-1, 6)
+    out = np.empty(len(obs))
+    lib().cheetah_oracle_reward(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
+                                C.c_double(dt_env), _p(out, C.c_double))
+    return out
+
+
+def cheetah_terminal(obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 18)
+    out = np.empty(len(obs), np.uint8)
+    lib().cheetah_oracle_terminal(C.c_int64(len(obs)), _p(obs, C.c_double), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
+def cheetah_inertia(q, v):
+    """(M [9,9], bias [9], energy) at one configuration: diagnostics for the tests."""
+    q = np.ascontiguousarray(q, np.float64).reshape(9)
+    v = np.ascontiguousarray(v, np.float64).reshape(9)
+    M = np.empty((9, 9))
+    b = np.empty(9)
+    e = C.c_double()
+    lib().cheetah_oracle_inertia(_p(q, C.c_double), _p(v, C.c_double), _p(M, C.c_double), _p(b, C.c_double), C.byref(e))
+    return M, b, e.value
