@@ -27,6 +27,7 @@ struct emei_env {
     uint32_t* frozen_episode;
     bool has_state, frozen;
     PendParams pend;
+    const void* trig;
 };
 
 static thread_local char g_err[512] = "";
@@ -63,6 +64,41 @@ extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, in
     if (act_dim) *act_dim = ad;
     if (state_dim) *state_dim = sd;
     return EMEI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// {sin, cos}(k * 2pi/256), k = 0..255, correctly rounded from long double, one copy per device.
+// Allocated on the first emei_create / stateless call for that device (never inside a hot launch
+// path of an existing handle).
+#include <mutex>
+namespace emei {
+const void* emei_trig_table(int device) {
+    static std::mutex mu;
+    static void* tabs[64] = {nullptr};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tabs[device]) {
+        SinCosEntry host[kTrigTableSize];
+        for (int k = 0; k < kTrigTableSize; ++k) {
+            const long double a = 2.0L * 3.141592653589793238462643383279502884L * k / kTrigTableSize;
+            host[k].s = (double)sinl(a), host[k].c = (double)cosl(a);
+        }
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        void* d = nullptr;
+        if (hipSetDevice(device) == hipSuccess && hipMalloc(&d, sizeof(host)) == hipSuccess &&
+            hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) == hipSuccess)
+            tabs[device] = d;
+        (void)hipSetDevice(prev);
+    }
+    return tabs[device];
+}
+}  // namespace emei
+
+static const void* current_device_trig() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return emei_trig_table(dev);
 }
 
 static bool is_pend(int env_id) { return env_id >= EMEI_CARTPOLE_SWINGUP && env_id <= EMEI_IP_BOUNDARY_SWINGUP; }
@@ -149,6 +185,11 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
         return fail(EMEI_ERR_HIP, "emei_create: allocation failed: %s", hipGetErrorString(e));
     }
     if (is_pend(cfg->env_id)) h->pend = pend_params(cfg->env_id, cfg->real_time_scale, cfg->init_noise);
+    h->trig = emei_trig_table(cfg->device);
+    if (!h->trig) {
+        emei_destroy(h);
+        return fail(EMEI_ERR_HIP, "emei_create: could not build the trig table on device %d", cfg->device);
+    }
     *out = h;
     return EMEI_OK;
 }
@@ -180,6 +221,7 @@ static PendLaunch pend_base(emei_env* h, void* stream) {
     L.seed = h->cfg.seed;
     L.env_offset = h->cfg.env_index_offset;
     L.p = h->pend;
+    L.trig = h->trig;
     L.stream = (hipStream_t)stream;
     return L;
 }
@@ -321,6 +363,7 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
         L.reward_out = reward_out;
         L.n = n;
         L.p = pend_params(env_id, real_time_scale > 0 ? real_time_scale : 0.02, 0.0);
+        L.trig = current_device_trig();
         L.stream = (hipStream_t)stream;
         int rc = pend_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
@@ -345,6 +388,7 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
         L.done_out = terminal_out;
         L.n = n;
         L.p = pend_params(env_id, 0.02, 0.0);
+        L.trig = current_device_trig();
         L.stream = (hipStream_t)stream;
         int rc = pend_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
@@ -375,6 +419,7 @@ extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, c
     L.n = n;
     L.freq_rate = freq_rate;
     L.p = pend_params(env_id, real_time_scale, 0.0);
+    L.trig = current_device_trig();
     L.stream = (hipStream_t)stream;
     int rc = pend_launch(L);
     return rc == EMEI_OK ? rc : fail(rc, "emei_next_obs: launch failed");

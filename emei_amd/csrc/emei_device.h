@@ -30,6 +30,75 @@ __device__ __forceinline__ void sincos_r(T x, T& s, T& c) {
     sincos_repair_r(x, s, c);
 }
 
+// Trig context of the cart/pole kernels: float64 uses the 256-entry {sin,cos} table every kernel
+// stages in LDS (emei_math.h: fast_sincos_tab); float32 keeps the polynomial kernels.
+struct TrigCtx {
+    const SinCosEntry* tab;  // LDS
+};
+__device__ __forceinline__ void sincos_fast_ctx(const TrigCtx& t, double x, double& s, double& c) {
+    fast_sincos_tab(x, t.tab, s, c);
+}
+__device__ __forceinline__ void sincos_fast_ctx(const TrigCtx&, float x, float& s, float& c) { fast_sincosf(x, s, c); }
+// Two-phase form for the substep: begin as soon as the new angle exists, end after the dynamics, so
+// that the table read's LDS latency (~100 cycles with bank conflicts) hides under ~25 float64
+// operations.  hipcc sinks an ordinary LDS load down to its first use and is free to move pure
+// arithmetic across a sched_barrier at the IR level, so the read and its wait are written as asm
+// and pinned by data dependencies: `pin(a, b)` makes (a, b) depend on the issued read (work that
+// consumes them cannot be hoisted above it), `end(after0, after1)` waits only once those values exist.
+// An asm LDS read is invisible to hipcc's lgkmcnt bookkeeping, which is safe here: LDS operations of a
+// wave return in order, so an uncounted extra read can only make a compiler-placed wait conservative.
+typedef double emei_d2 __attribute__((ext_vector_type(2)));
+struct TrigPendingF64 {
+    emei_d2 e;  // {sin, cos}(k 2pi/256), in flight until end()
+    double sr, cr;
+};
+struct TrigPendingF32 {
+    float s, c;
+};
+__device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, double x) {
+    const double inv_step = 40.74366543152521;                                    // 256 / (2 pi)
+    const double H1 = 1.5707963267948966 / 64, H2 = 6.123233995736766e-17 / 64;  // 2pi/256 = H1 + H2
+    TrigPendingF64 p;
+    const double n = __builtin_rint(x * inv_step);
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)t.tab +
+                          (((uint32_t)(int)n & (uint32_t)(kTrigTableSize - 1)) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
+    double r = __builtin_fma(-n, H1, x);
+    r = __builtin_fma(-n, H2, r);
+    const double z = r * r;
+    p.sr = __builtin_fma(r * z, __builtin_fma(z, 1.0 / 120, -1.0 / 6), r);
+    p.cr = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
+    return p;
+}
+__device__ __forceinline__ void sincos_pin(const TrigPendingF64& p, double& a, double& b) {
+    asm volatile("" : "+v"(a), "+v"(b) : "v"(p.e));
+}
+__device__ __forceinline__ void sincos_end_ctx(TrigPendingF64& p, double after0, double after1, double& s, double& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.e) : "v"(after0), "v"(after1));
+    s = __builtin_fma(p.e.x, p.cr, p.e.y * p.sr);
+    c = __builtin_fma(p.e.y, p.cr, -(p.e.x * p.sr));
+}
+__device__ __forceinline__ TrigPendingF32 sincos_begin_ctx(const TrigCtx&, float x) {
+    TrigPendingF32 p;
+    fast_sincosf(x, p.s, p.c);
+    return p;
+}
+__device__ __forceinline__ void sincos_pin(const TrigPendingF32&, float&, float&) {}
+__device__ __forceinline__ void sincos_end_ctx(TrigPendingF32& p, float, float, float& s, float& c) { s = p.s, c = p.c; }
+
+template <typename T>
+__device__ __forceinline__ void sincos_ctx(const TrigCtx& t, T x, T& s, T& c) {
+    sincos_fast_ctx(t, x, s, c);
+    sincos_repair_r(x, s, c);
+}
+// every thread of the 256-thread block copies one entry; the barrier must be reached by ALL threads
+// (callers stage the table before any early return)
+__device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src) {
+    static_assert(kBlock == kTrigTableSize, "one table entry per thread");
+    lds[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+}
+
 // hardware reciprocal seed + Newton (emei_math.h)
 __device__ __forceinline__ double rcp_r(double d) { return refine_rcp(d, __builtin_amdgcn_rcp(d)); }
 __device__ __forceinline__ float rcp_r(float d) { return 1.0f / d; }

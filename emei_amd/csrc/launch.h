@@ -17,6 +17,7 @@ struct PendLaunch {
     uint32_t* episode = nullptr;
     unsigned long long* done_mask = nullptr;
     const void* actions = nullptr;
+    const void* trig = nullptr;  // device {sin,cos} table (emei_trig_table)
     const float* obs_in = nullptr;
     float* obs_out = nullptr;
     double* obs_f64 = nullptr;
@@ -32,6 +33,9 @@ struct PendLaunch {
 
 // pendulum_kernels.hip
 int pend_launch(const PendLaunch& L);
+
+// abi.hip: the per-device 256-entry {sin,cos} table (allocated and filled on first use)
+const void* emei_trig_table(int device);
 
 // util_kernels.hip
 int launch_state_unpack(const double* aos, void* soa, int precision, int64_t n, int dim, hipStream_t s);

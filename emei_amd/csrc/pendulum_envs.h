@@ -38,6 +38,7 @@ struct CartPole {
     static constexpr int kActDim = 1;
     struct Carry {
         R sn, cs;
+        TrigCtx trig;
     };
     using Action = R;  // force / total_mass
     // only the float32 time step reaches the kernel: a small argument block leaves the scalar
@@ -65,7 +66,7 @@ struct CartPole {
     }
 
     __device__ __forceinline__ static void prime(const R s[4], Carry& c, const Params&) {
-        sincos_r(s[2], c.sn, c.cs);
+        sincos_ctx(c.trig, s[2], c.sn, c.cs);
     }
 
     // One explicit-Euler substep: cartpole.py:48-60 (_dsdt) + base_control.py:162-164.
@@ -86,8 +87,9 @@ struct CartPole {
         // accelerations: issue it first and let it overlap the dynamics below
         s[0] += (R)__fmul_rn((float)x_dot, p.dt32);
         s[2] += (R)__fmul_rn((float)theta_dot, p.dt32);
-        const R sn = c.sn, cs = c.cs;
-        sincos_fast_r(s[2], c.sn, c.cs);
+        R sn = c.sn, cs = c.cs;
+        auto pending = sincos_begin_ctx(c.trig, s[2]);  // table read in flight under the dynamics
+        sincos_pin(pending, sn, cs);
         R temp = fma_r(A * (theta_dot * theta_dot), sn, force_over_m);
         R num = fma_r(gravity, sn, -(cs * temp));
         R den = fma_r(-B, cs * cs, L43);
@@ -97,6 +99,7 @@ struct CartPole {
         // (base_control.py:164, weak-scalar promotion), accumulated in R (float64 in the reference)
         s[1] += (R)__fmul_rn((float)x_acc, p.dt32);
         s[3] += (R)__fmul_rn((float)theta_acc, p.dt32);
+        sincos_end_ctx(pending, x_acc, theta_acc, c.sn, c.cs);
         sincos_repair_r(s[2], c.sn, c.cs);  // |theta| > 1e6 only; after the straight-line block
     }
 
@@ -154,6 +157,7 @@ struct InvPend {
     static constexpr int kActDim = 1;
     struct Carry {
         R sn, cs;  // of phi = theta + phi_off
+        TrigCtx trig;
     };
     using Action = R;  // clipped ctrl
     using Params = PendParams;
@@ -173,7 +177,7 @@ struct InvPend {
     }
 
     __device__ __forceinline__ static void prime(const R s[4], Carry& c, const PendParams& p) {
-        sincos_r(s[1] + (R)p.phi_off, c.sn, c.cs);
+        sincos_ctx(c.trig, s[1] + (R)p.phi_off, c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void substep(R s[4], Carry& c, R u, const PendParams& p) {
@@ -214,7 +218,7 @@ struct InvPend {
         s[1] = fma_r(dt, s[3], s[1]);
         s[2] = fma_r(dt, a0, s[2]);    // MuJoCo Euler on qvel (no joint damping in this model)
         s[3] = fma_r(dt, a1, s[3]);
-        sincos_r(s[1] + (R)p.phi_off, c.sn, c.cs);
+        sincos_ctx(c.trig, s[1] + (R)p.phi_off, c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {

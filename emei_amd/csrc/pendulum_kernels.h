@@ -20,6 +20,7 @@ struct RolloutArgs {
     uint32_t* episode;          // per-env episode counter (RNG counter word)
     unsigned long long* done_mask;  // one ballot word per wave: done of the LAST step
     const void* actions;
+    const SinCosEntry* trig;  // 256-entry {sin,cos} table in device memory (abi.hip: emei_trig_table)
     float4* obs_out;
     float* reward_out;
     uint8_t* done_out;
@@ -37,6 +38,8 @@ struct RolloutArgs {
 template <class Env, typename ActT, bool FULL>
 __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<Env> a) {
     using R = typename Env::real;
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, a.trig);
     const ActT* __restrict__ actions = (const ActT*)a.actions;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -49,6 +52,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
     int32_t steps = a.steps[i];
     uint32_t episode = a.episode[i];
     typename Env::Carry c;
+    c.trig.tab = trig_s;
     Env::prime(s, c, a.p);
 
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
@@ -145,6 +149,8 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     __shared__ float rew_s[kWavesPerBlock][4][kWave];
     __shared__ uint8_t done_s[kWavesPerBlock][kStage][kWave];
 
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, a.trig);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
     if (i >= a.n) return;
@@ -158,6 +164,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     int32_t steps = a.steps[i];
     uint32_t episode = a.episode[i];
     typename Env::Carry c;
+    c.trig.tab = trig_s;
     Env::prime(s, c, a.p);
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
     const int last = a.n_steps - 1;
@@ -325,8 +332,10 @@ __global__ void __launch_bounds__(kBlock)
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
     pend_reward_terminal_kernel(const float4* obs, float* reward, uint8_t* terminal, int64_t n,
-                                typename Env::Params p) {
+                                typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, trig);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 v = obs[i];
@@ -334,6 +343,7 @@ __global__ void __launch_bounds__(kBlock)
     // the observation IS the state for reward/terminal purposes (wrapped angle has the same cosine);
     // build the carry from it.  For InvertedPendulum o[1] is theta, prime() adds phi_off itself.
     typename Env::Carry c;
+    c.trig.tab = trig_s;
     Env::prime(o, c, p);
     if (reward) reward[i] = (float)Env::reward(o, c, p);
     if (terminal) terminal[i] = (uint8_t)Env::terminal(o, c, p);
@@ -343,14 +353,17 @@ __global__ void __launch_bounds__(kBlock)
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
     pend_next_obs_kernel(const float4* obs, const void* actions, int action_dtype, float4* next_obs, int64_t n,
-                         int freq_rate, typename Env::Params p) {
+                         int freq_rate, typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, trig);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 v = obs[i];
     R s[4] = {(R)v.x, (R)v.y, (R)v.z, (R)v.w}, o[4], rew;
     bool term;
     typename Env::Carry c;
+    c.trig.tab = trig_s;
     Env::prime(s, c, p);
     Env::step(s, c, Env::load_action(actions, action_dtype, i), p, freq_rate, o, rew, term);
     next_obs[i] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
@@ -387,6 +400,7 @@ static int launch_env(const PendLaunch& L) {
     a.episode = L.episode;
     a.done_mask = L.done_mask;
     a.actions = L.actions;
+    a.trig = (const SinCosEntry*)L.trig;
     a.obs_out = (float4*)L.obs_out;
     a.reward_out = L.reward_out;
     a.done_out = L.done_out;
@@ -423,11 +437,11 @@ static int launch_env(const PendLaunch& L) {
             break;
         case PEND_OP_REWARD_TERMINAL:
             hipLaunchKernelGGL(pend_reward_terminal_kernel<Env>, grid, dim3(kBlock), 0, L.stream,
-                               (const float4*)L.obs_in, L.reward_out, L.done_out, L.n, a.p);
+                               (const float4*)L.obs_in, L.reward_out, L.done_out, L.n, a.p, a.trig);
             break;
         case PEND_OP_NEXT_OBS:
             hipLaunchKernelGGL(pend_next_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (const float4*)L.obs_in,
-                               L.actions, L.action_dtype, (float4*)L.obs_out, L.n, L.freq_rate, a.p);
+                               L.actions, L.action_dtype, (float4*)L.obs_out, L.n, L.freq_rate, a.p, a.trig);
             break;
         default: return EMEI_ERR_INVALID;
     }

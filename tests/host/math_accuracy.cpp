@@ -24,6 +24,26 @@ int main() {
         }
         printf("f64 range %g maxabs %.3e\n", R, worst);
     }
+    {   // table-assisted variant with a correctly rounded table (as emei_trig_table builds it)
+        static emei::SinCosEntry tab[emei::kTrigTableSize];
+        for (int k = 0; k < emei::kTrigTableSize; ++k) {
+            long double a = 2.0L * 3.141592653589793238462643383279502884L * k / emei::kTrigTableSize;
+            tab[k].s = (double)sinl(a), tab[k].c = (double)cosl(a);
+        }
+        for (double R : ranges) {
+            std::uniform_real_distribution<double> U(-R, R);
+            double worst = 0;
+            for (int i = 0; i < 400000; ++i) {
+                double x = U(rng), s, c;
+                emei::fast_sincos_tab(x, tab, s, c);
+                long double es = std::fabs((long double)s - sinl((long double)x));
+                long double ec = std::fabs((long double)c - cosl((long double)x));
+                if (es > worst) worst = (double)es;
+                if (ec > worst) worst = (double)ec;
+            }
+            printf("tab range %g maxabs %.3e\n", R, worst);
+        }
+    }
     // near multiples of pi/2 (cancellation in the reduction)
     {
         double worst = 0;

@@ -15,9 +15,11 @@ def test_fast_sincos_and_division_accuracy():
                                os.path.join(ROOT, "tests", "host", "math_accuracy.cpp")])
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     f64 = [float(x) for x in re.findall(r"f64 .*maxabs ([0-9.e+-]+)", out)]
+    tab = [float(x) for x in re.findall(r"tab .*maxabs ([0-9.e+-]+)", out)]
     f32 = [float(x) for x in re.findall(r"f32 .*maxabs ([0-9.e+-]+)", out)]
     div = float(re.search(r"div maxrel ([0-9.e+-]+)", out).group(1))
     assert len(f64) == 7 and max(f64) <= 2.0e-16, out
+    assert len(tab) == 6 and max(tab) <= 2.0e-16, out  # the 256-entry table variant the float64 kernels use
     assert len(f32) == 5 and max(f32) <= 1.0e-7, out
     assert div <= 2.3e-16, out
     assert "inf -> nan nan" in out and "nan -> nan nan" in out
