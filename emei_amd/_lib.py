@@ -64,6 +64,8 @@ SYMBOLS = {
     "emei_step": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
     "emei_rollout": (C.c_int, [_vp, _i32, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
     "emei_compact_done": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "emei_get_counters": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "emei_episode_init_obs": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "emei_reward": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _dbl, _i32, _vp, _vp]),
     "emei_terminal": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp]),
     "emei_next_obs": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _vp, _vp]),

@@ -350,6 +350,35 @@ extern "C" EMEI_API int emei_compact_done(emei_env* h, int32_t* idx_out, int32_t
     return rc == EMEI_OK ? rc : fail(rc, "emei_compact_done: launch failed");
 }
 
+extern "C" EMEI_API int emei_get_counters(emei_env* h, int32_t* steps_out, uint32_t* episode_out, void* stream) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_get_counters: null handle");
+    const size_t n = (size_t)h->cfg.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, h->steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (episode_out) HIP_TRY(hipMemcpyAsync(episode_out, h->episode, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const int64_t* env_index, const uint32_t* episode,
+                                              float* obs_out, void* stream) {
+    if (!h || !env_index || !episode || !obs_out) return fail(EMEI_ERR_INVALID, "emei_episode_init_obs: null argument");
+    if (count <= 0) return fail(EMEI_ERR_INVALID, "emei_episode_init_obs: count=%lld", (long long)count);
+    int rc;
+    if (is_pend(h->cfg.env_id)) {
+        PendLaunch L = pend_base(h, stream);
+        L.op = PEND_OP_INIT_OBS;
+        L.n = count;
+        L.env_index = env_index;
+        L.episode_in = episode;
+        L.obs_out = obs_out;
+        rc = pend_launch(L);
+    } else {
+        rc = cheetah_init_obs(count, env_index, episode, h->cfg.seed, h->cfg.env_index_offset, h->cfg.init_noise, obs_out,
+                              (hipStream_t)stream);
+    }
+    return rc == EMEI_OK ? rc : fail(rc, "emei_episode_init_obs: launch failed");
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
                            double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {

@@ -146,6 +146,17 @@ __global__ void __launch_bounds__(kBlock)
     episode[i] = 0;
 }
 
+__global__ void __launch_bounds__(kBlock)
+    cheetah_init_obs_kernel(const int64_t* env_index, const uint32_t* episode, float* obs, int64_t count, uint64_t seed,
+                            uint64_t env_offset, float sigma) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    double q[NV], v[NV];
+    cheetah_init(q, v, seed, env_offset + (uint64_t)env_index[k], episode[k], sigma);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) obs[k * kObs + j] = (float)q[j], obs[k * kObs + NV + j] = (float)v[j];
+}
+
 struct CheetahArgs {
     void* state;
     int32_t* steps;
@@ -309,6 +320,14 @@ int cheetah_reward(int64_t n, const float* obs, const float* pre_obs, const floa
 int cheetah_terminal(int64_t n, const float* obs, uint8_t* terminal_out, hipStream_t s) {
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(cheetah_terminal_kernel, grid, dim3(kBlock), 0, s, obs, terminal_out, n);
+    return hipGetLastError() == hipSuccess ? EMEI_OK : EMEI_ERR_HIP;
+}
+
+int cheetah_init_obs(int64_t count, const int64_t* env_index, const uint32_t* episode, uint64_t seed, uint64_t env_offset,
+                     double init_noise, float* obs_out, hipStream_t s) {
+    dim3 grid((unsigned)((count + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(cheetah_init_obs_kernel, grid, dim3(kBlock), 0, s, env_index, episode, obs_out, count, seed,
+                       env_offset, (float)init_noise);
     return hipGetLastError() == hipSuccess ? EMEI_OK : EMEI_ERR_HIP;
 }
 

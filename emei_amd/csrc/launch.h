@@ -7,7 +7,7 @@
 
 namespace emei {
 
-enum PendOp { PEND_OP_ROLLOUT = 0, PEND_OP_RESET, PEND_OP_GET_OBS, PEND_OP_REWARD_TERMINAL, PEND_OP_NEXT_OBS };
+enum PendOp { PEND_OP_ROLLOUT = 0, PEND_OP_RESET, PEND_OP_GET_OBS, PEND_OP_REWARD_TERMINAL, PEND_OP_NEXT_OBS, PEND_OP_INIT_OBS };
 
 struct PendLaunch {
     int op = PEND_OP_ROLLOUT;
@@ -19,6 +19,8 @@ struct PendLaunch {
     const void* actions = nullptr;
     const void* trig = nullptr;  // device {sin,cos} table (emei_trig_table)
     const float* obs_in = nullptr;
+    const int64_t* env_index = nullptr;  // PEND_OP_INIT_OBS
+    const uint32_t* episode_in = nullptr;
     float* obs_out = nullptr;
     double* obs_f64 = nullptr;
     float* reward_out = nullptr;

@@ -310,6 +310,20 @@ __global__ void __launch_bounds__(kBlock)
     episode[i] = 0;
 }
 
+// initial observation of (env, episode) pairs under the device reset generator
+template <class Env>
+__global__ void __launch_bounds__(kBlock)
+    pend_init_obs_kernel(const int64_t* env_index, const uint32_t* episode, float4* obs, int64_t count, uint64_t seed,
+                         uint64_t env_offset, typename Env::Params p) {
+    using R = typename Env::real;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    R s[4], o[4];
+    Env::init(s, seed, env_offset + (uint64_t)env_index[k], episode[k], p);
+    Env::obs_of(s, o);
+    obs[k] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+}
+
 // current_obs as float64 [n,4]
 template <class Env>
 __global__ void __launch_bounds__(kBlock)
@@ -430,6 +444,10 @@ static int launch_env(const PendLaunch& L) {
         case PEND_OP_RESET:
             hipLaunchKernelGGL(pend_reset_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps,
                                L.episode, L.n, L.seed, L.env_offset, a.p);
+            break;
+        case PEND_OP_INIT_OBS:
+            hipLaunchKernelGGL(pend_init_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, L.env_index, L.episode_in,
+                               (float4*)L.obs_out, L.n, L.seed, L.env_offset, a.p);
             break;
         case PEND_OP_GET_OBS:
             hipLaunchKernelGGL(pend_get_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (const R*)L.state,

@@ -121,6 +121,22 @@ class Engine:
                 torch.empty(lead + (self.n_envs,), dtype=torch.float32, device=self.device),
                 torch.empty(lead + (self.n_envs,), dtype=torch.uint8, device=self.device))
 
+    def get_counters(self):
+        """(steps since reset int32 [N], episode index int64 [N])."""
+        steps = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        epi = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)  # uint32 payload
+        L.check(L.lib().emei_get_counters(self._h, _ptr(steps), _ptr(epi), _stream()))
+        return steps, epi.to(torch.int64) & 0xFFFFFFFF
+
+    def episode_init_obs(self, env_index, episode):
+        """Initial observation of the device reset for (env, episode) pairs -> [count, obs_dim] float32."""
+        env_index = env_index.to(device=self.device, dtype=torch.int64).contiguous()
+        epi = (episode.to(device=self.device, dtype=torch.int64) & 0xFFFFFFFF).to(torch.int32).contiguous()  # uint32 payload
+        out = torch.empty((env_index.numel(), self.obs_dim), dtype=torch.float32, device=self.device)
+        if env_index.numel():
+            L.check(L.lib().emei_episode_init_obs(self._h, env_index.numel(), _ptr(env_index), _ptr(epi), _ptr(out), _stream()))
+        return out
+
     def compact_done(self):
         """Sorted indices of the envs that were done at the last step (int32 tensor)."""
         idx = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)

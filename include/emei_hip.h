@@ -134,6 +134,17 @@ EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* actions, int
  * count_out [1] int32. */
 EMEI_API int emei_compact_done(emei_env* h, int32_t* idx_out, int32_t* count_out, void* stream);
 
+/* Per-env counters of the handle: steps since the last reset (TimeLimit) and the episode index (the
+ * counter word of the device reset generator).  Either pointer may be NULL. */
+EMEI_API int emei_get_counters(emei_env* h, int32_t* steps_out, uint32_t* episode_out, void* stream);
+
+/* Initial observation the DEVICE reset gives env `env_index[k]` (local index in this handle) at the
+ * start of episode `episode[k]`: what Env.reset() would return for that (env, episode) pair.  Used to
+ * rebuild `observations` after an auto-reset when a rollout is turned into an offline dataset
+ * (schema of zoo/util.py:16-30,62-67): obs_out [count, obs_dim] float32. */
+EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const int64_t* env_index, const uint32_t* episode,
+                                   float* obs_out, void* stream);
+
 /* -- stateless batched reward / terminal (model-based-RL callers) ---------------------------- */
 /* EmeiEnv.get_batch_reward / get_batch_terminal (core.py:182-188; cartpole.py:124-129,145-151;
  * inverted_pendulum.py:73-183; half_cheetah.py:59-67): obs, pre_obs [n, obs_dim] float32,
