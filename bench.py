@@ -92,13 +92,19 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("EMEI_BENCH_SHARE_GPU"):  # rehearsal of the N>1 path on a one-GPU box (gloo, ranks share cuda:0)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EMEI_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if not os.path.exists(os.path.join(ROOT, "emei_amd", "libemei_hip.so")):
         if rank == 0:

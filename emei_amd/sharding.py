@@ -27,6 +27,12 @@ def allgather_obs(local_obs, group=None, out=None):
     if out is None:
         out = torch.empty((world * local_obs.shape[0],) + tuple(local_obs.shape[1:]), dtype=local_obs.dtype,
                           device=local_obs.device)
+    if dist.get_backend(group) == "gloo" and local_obs.is_cuda:
+        # rehearsal path only (gloo has no device all-gather): stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local_obs.cpu().contiguous(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local_obs.contiguous(), group=group)
     return out
 
