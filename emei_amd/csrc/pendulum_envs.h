@@ -182,20 +182,29 @@ struct InvPend {
 
     __device__ __forceinline__ static void substep(R s[4], Carry& c, R u, const PendParams& p) {
         const R M11 = (R)p.M11, M22 = (R)p.M22;
-        R M12 = (R)p.mpr * c.cs;
+        const R dt = (R)p.dt;
+        // the new angle needs only the OLD angular velocity (get_euler_pos, mujoco_env.py:189-191), so its
+        // sin/cos is started first and lands under the dynamics (see CartPole::substep)
+        const R x_old = s[0], v_old = s[2], om_old = s[3];
+        s[0] = fma_r(dt, v_old, x_old);
+        s[1] = fma_r(dt, om_old, s[1]);
+        R sn = c.sn, cs = c.cs;
+        auto pending = sincos_begin_ctx(c.trig, s[1] + (R)p.phi_off);
+        sincos_pin(pending, sn, cs);
+        R M12 = (R)p.mpr * cs;
         R ctrl = u < (R)p.ctrl_lo ? (R)p.ctrl_lo : (u > (R)p.ctrl_hi ? (R)p.ctrl_hi : u);  // ctrllimited
-        R f1 = (R)p.gear * ctrl + (R)p.mpr * c.sn * s[3] * s[3];
-        R f2 = (R)p.mgr * c.sn;
+        R f1 = (R)p.gear * ctrl + (R)p.mpr * sn * om_old * om_old;
+        R f2 = (R)p.mgr * sn;
         R det = fma_r(-M12, M12, M11 * M22);
         R idet = rcp_r(det);
         R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
         R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
         // soft slider-limit constraint (MuJoCo joint limit, default solref/solimp)
         R dist = R(0), J = R(0);
-        if (s[0] - (R)p.x_lo < R(0)) {
-            dist = s[0] - (R)p.x_lo, J = R(1);
-        } else if ((R)p.x_hi - s[0] < R(0)) {
-            dist = (R)p.x_hi - s[0], J = R(-1);
+        if (x_old - (R)p.x_lo < R(0)) {
+            dist = x_old - (R)p.x_lo, J = R(1);
+        } else if ((R)p.x_hi - x_old < R(0)) {
+            dist = (R)p.x_hi - x_old, J = R(-1);
         }
         if (J != R(0)) {
             R tc = (R)p.tc;
@@ -204,7 +213,7 @@ struct InvPend {
             R imp = (R)p.dmin + y * ((R)p.dmax - (R)p.dmin);
             R K = R(1) / ((R)p.dmax * (R)p.dmax * tc * tc * (R)p.dampratio * (R)p.dampratio);
             R B = R(2) / ((R)p.dmax * tc);
-            R aref = -B * (J * s[2]) - K * imp * dist;
+            R aref = -B * (J * v_old) - K * imp * dist;
             R A = M22 * idet;
             R Rr = (R(1) - imp) / imp * (R)p.invw;
             R force = (aref - J * a0) / (A + Rr);
@@ -213,12 +222,10 @@ struct InvPend {
                 a1 += (-M12 * idet) * J * force;
             }
         }
-        R dt = (R)p.dt;
-        s[0] = fma_r(dt, s[2], s[0]);  // get_euler_pos, mujoco_env.py:189-191: old velocity
-        s[1] = fma_r(dt, s[3], s[1]);
-        s[2] = fma_r(dt, a0, s[2]);    // MuJoCo Euler on qvel (no joint damping in this model)
-        s[3] = fma_r(dt, a1, s[3]);
-        sincos_ctx(c.trig, s[1] + (R)p.phi_off, c.sn, c.cs);
+        s[2] = fma_r(dt, a0, v_old);   // MuJoCo Euler on qvel (no joint damping in this model)
+        s[3] = fma_r(dt, a1, om_old);
+        sincos_end_ctx(pending, a0, a1, c.sn, c.cs);
+        sincos_repair_r(s[1] + (R)p.phi_off, c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
