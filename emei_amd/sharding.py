@@ -84,7 +84,7 @@ class ShardedRollout:
         self.seed = seed
         self.actions = self.out = self.gathered = None
         self._events = []
-        self.kernel_name = "pend_rollout_kernel" if env != "HalfCheetahRunning" else "cheetah_rollout_kernel"
+        self.kernel_name = "pend_rollout_staged_kernel" if env != "HalfCheetahRunning" else "cheetah_rollout_kernel"
 
     @property
     def action_bytes(self):

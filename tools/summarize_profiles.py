@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into the
+tracked summaries under profiles/: <round>_<workload>_kernel_stats.csv, <round>_<workload>_pmc.txt and
+profiles/traffic.json (HBM bytes per launch with the gfx950 FETCH_SIZE correction of
+MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests of a wide coalesced stream as 64 B -> x2;
+WRITE_SIZE is exact for 16 B/lane stores; both are in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mean_counters(d, pat):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    raw, rnd, workload, pat = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    n_envs, horizon, bytes_per_step, waves = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    stats = glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(ROOT, "profiles", f"{rnd}_{workload}_kernel_stats.csv"))
+    krow = [r for r in csv.DictReader(open(stats)) if pat in r["Name"]][0]
+    fetch = mean_counters(os.path.join(raw, "fetch"), pat).get("FETCH_SIZE")
+    write = mean_counters(os.path.join(raw, "write"), pat).get("WRITE_SIZE")
+    sq = mean_counters(os.path.join(raw, "sq"), pat)
+    alg = bytes_per_step * n_envs * horizon
+    traffic = (2 * fetch + write) * 1024
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    allj = json.load(open(tj)) if os.path.exists(tj) else {}
+    allj[workload] = {
+        "bytes_per_launch": traffic, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+        "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B; MI355X_MICROARCH.md, HBM section)",
+        "algorithmic_bytes_per_launch": alg, "ratio_traffic_over_algorithmic": traffic / alg,
+        "rocprof_kernel_avg_us": float(krow["AverageNs"]) / 1e3, "rocprof_kernel_min_us": float(krow["MinNs"]) / 1e3,
+        "rocprof_kernel_calls": int(krow["Calls"]), "profile": f"profiles/{rnd}_{workload}_*",
+    }
+    json.dump(allj, open(tj, "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc.txt"), "w") as fo:
+        fo.write(f"rocprofv3 PMC summary ({rnd}), bench.py workload {workload}: {n_envs} envs x {horizon} steps per launch, REF (f64)\n")
+        fo.write(f"kernel: {krow['Name'][:140]}\n")
+        fo.write(f"kernel-trace --stats: {krow['Calls']} calls, avg {float(krow['AverageNs'])/1e3:.1f} us, min {float(krow['MinNs'])/1e3:.1f}, max {float(krow['MaxNs'])/1e3:.1f}\n\n")
+        fo.write(f"pass --pmc FETCH_SIZE : {fetch:.1f} KiB raw -> x2 gfx950 correction = {2*fetch*1024/1e6:.1f} MB read per launch\n")
+        fo.write(f"pass --pmc WRITE_SIZE : {write:.1f} KiB     = {write*1024/1e6:.1f} MB written per launch\n")
+        fo.write(f"HBM traffic per launch: {traffic/1e6:.1f} MB (algorithmic {bytes_per_step} B x {n_envs*horizon/1e6:.3f}e6 env-steps = {alg/1e6:.1f} MB; ratio {traffic/alg:.3f})\n\n")
+        fo.write("pass SQ counters (sum over all waves; WAVE_CYCLES / WAIT_* / ACTIVE_* are quad-cycles)\n")
+        for k, v in sorted(sq.items()):
+            fo.write(f"   {k:24s} {v:18.1f}\n")
+        w = sq["SQ_WAVE_CYCLES"]
+        per = waves * horizon
+        fo.write(f"\n   per wave per env-step: VALU {sq['SQ_INSTS_VALU']/per:.1f}  SALU {sq['SQ_INSTS_SALU']/per:.1f}  LDS {sq['SQ_INSTS_LDS']/per:.2f} instructions; {4*w/per:.0f} cycles\n")
+        fo.write(f"   wave time split: issuing {sq['SQ_ACTIVE_INST_ANY']/w:.1%}  parked at s_waitcnt {sq['SQ_WAIT_ANY']/w:.1%}  issue stall {sq['SQ_WAIT_INST_ANY']/w:.1%}\n")
+    print(open(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc.txt")).read())
+
+
+if __name__ == "__main__":
+    main()
