@@ -1,84 +1,88 @@
-"""Host-side mirror of emei's core API (reference: emei/core.py).
+"""Host-side API surface of emei's core classes, re-implemented for the HIP engine.
 
-Same names, argument meaning and error behaviour as the reference's ``Freezable`` / ``OfflineEnv`` /
-``EmeiEnv`` for the env-step path; the dataset download plumbing (core.py:60-128) is out of scope
-(network fetch) and raises.
+Reference behaviour kept (file:line under /root/reference/emei/core.py):
+  * ``Freezable`` (:18-37): a ``frozen`` flag with assertions on double freeze / unfreeze.
+  * ``OfflineEnv`` (:40-58): ``env_name`` = class name without the "Env" suffix, ``env_params_name`` =
+    "&"-joined ``key=value`` pairs in sorted key order (the string test/test_core.py pins).
+    The download / h5 plumbing (:60-128) is a network fetch and is not part of the env-step path.
+  * ``EmeiEnv`` (:131-193): causal-graph getters and the abstract batched functions.
 """
-from abc import abstractmethod
-from typing import Dict, Union
-
 import numpy as np
 
 
 class Freezable:
-    """core.py:18-37."""
+    """Snapshot switch used by model-based callers: freeze() -> query -> unfreeze()."""
+
+    frozen_state = None
+    frozen = False
 
     def __init__(self):
-        self.frozen_state = None
-        self.frozen = False
+        self.frozen_state, self.frozen = None, False
+
+    def _flip(self, to, complaint):
+        assert self.frozen != to, complaint
+        self.frozen = to
 
     def freeze(self):
-        assert not self.frozen, "env has frozen"
-        self.frozen = True
+        self._flip(True, "env has frozen")
 
     def unfreeze(self):
-        assert self.frozen, "env has unfrozen"
-        self.frozen = False
+        self._flip(False, "env has unfrozen")
 
 
 class OfflineEnv:
-    """core.py:40-128 without the network plumbing."""
+    """Naming metadata that keys the reference's offline datasets."""
 
     metadata = {}
 
-    def __init__(self, env_params: Dict[str, Union[str, int, float]]):
-        self.env_name = self.__class__.__name__[:-3]  # strip "Env" (core.py:42)
+    def __init__(self, env_params):
+        cls = type(self).__name__
+        self.env_name = cls[:-3]  # "CartPoleSwingUpEnv" -> "CartPoleSwingUp"
         self.env_params = env_params
-        self._offline_dataset_urls = {}
-        self._offline_dataset_names = []
+        self._offline_dataset_names, self._offline_dataset_urls = [], {}
 
     @property
-    def dataset_names(self) -> list:
+    def dataset_names(self):
         return self._offline_dataset_names
 
     @property
     def env_params_name(self):
-        """core.py:56-58: '&'.join('k=v' for sorted k)."""
-        return "&".join("{}={}".format(key, self.env_params[key]) for key in sorted(self.env_params.keys()))
+        params = self.env_params
+        return "&".join(f"{k}={params[k]}" for k in sorted(params))
 
-    def get_dataset(self, dataset_name: str):
+    def get_dataset(self, dataset_name):
         raise NotImplementedError(
-            "offline datasets are fetched over the network by the reference (core.py:95-128); "
-            "use emei_amd.datasets.collect() to generate them on the GPU instead"
+            f"dataset {dataset_name!r}: the reference downloads datasets from the network (core.py:95-128), "
+            "which this build never does; generate one on the GPU with emei_amd.datasets.collect()"
         )
 
 
 class EmeiEnv(Freezable, OfflineEnv):
-    """core.py:131-193."""
+    """Base of every env: graphs + the batched reward / terminal / init / next-obs interface."""
 
-    def __init__(self, env_params: Dict[str, Union[str, int, float]]):
+    def __init__(self, env_params):
         Freezable.__init__(self)
         OfflineEnv.__init__(self, env_params=env_params)
-        self._transition_graph = None
-        self._reward_mech_graph = None
-        self._termination_mech_graph = None
+        self._transition_graph = self._reward_mech_graph = self._termination_mech_graph = None
 
+    # -- causal metadata ---------------------------------------------------------------------------
     def get_transition_graph(self, repeat_times=1):
-        """core.py:142-161: (n_obs+n_act) x n_obs 0/1 graph; repeat_times > 1 = reachability within
-        that many steps through repeated products of the square-augmented graph."""
-        g = self._transition_graph.copy()  # AttributeError on None, like the reference (CartPole defines no graph)
-        num_obs, num_action = self.observation_space.shape[0], self.action_space.shape[0]
-        assert g.shape == (num_obs + num_action, num_obs)
+        """0/1 matrix [(n_obs + n_act), n_obs]: entry (i, j) says variable i influences obs j within
+        `repeat_times` steps.  One step is the stored graph; more steps are walks of length <= k in the
+        graph extended by zero columns for the action rows (core.py:142-161), computed here as boolean
+        reachability instead of summed float matrix powers."""
+        graph = self._transition_graph.copy()  # raises on None exactly like the reference (CartPole has no graph)
+        n_obs, n_act = self.observation_space.shape[0], self.action_space.shape[0]
+        assert graph.shape == (n_obs + n_act, n_obs)
         if repeat_times == 1:
-            return g
-        aug_g = np.zeros([num_obs + num_action, num_obs + num_action])
-        aug_g[:, :num_obs] = g.copy()
-        prod_g = aug_g.copy()
-        sum_g = np.zeros([num_obs + num_action, num_obs + num_action])
+            return graph
+        step = np.zeros((n_obs + n_act, n_obs + n_act), dtype=bool)
+        step[:, :n_obs] = graph.astype(bool)
+        reach, walk = np.zeros_like(step), step.copy()
         for _ in range(repeat_times):
-            sum_g += prod_g
-            prod_g = np.matmul(prod_g, aug_g)
-        return (sum_g > 0).astype(int)[:, :num_obs]
+            reach |= walk
+            walk = (walk.astype(np.int64) @ step.astype(np.int64)) > 0
+        return reach[:, :n_obs].astype(int)
 
     def get_reward_mech_graph(self):
         return self._reward_mech_graph
@@ -86,28 +90,26 @@ class EmeiEnv(Freezable, OfflineEnv):
     def get_termination_mech_graph(self):
         return self._termination_mech_graph
 
+    # -- state <-> observation (identity unless an env overrides) -----------------------------------
     def transform_state_to_obs(self, batch_state):
         return batch_state.copy()
 
     def transform_obs_to_state(self, batch_obs):
         return batch_obs.copy()
 
-    @abstractmethod
+    # -- batched functions every concrete env provides ---------------------------------------------
     def get_batch_init_state(self, batch_size):
         raise NotImplementedError
 
     def get_batch_init_obs(self, batch_size):
         return self.transform_state_to_obs(self.get_batch_init_state(batch_size=batch_size))
 
-    @abstractmethod
     def get_batch_reward(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
         raise NotImplementedError
 
-    @abstractmethod
     def get_batch_terminal(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
         raise NotImplementedError
 
-    @abstractmethod
     def get_batch_next_obs(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
         assert self.frozen
         raise NotImplementedError

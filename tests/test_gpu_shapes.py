@@ -1,0 +1,88 @@
+"""Ragged and boundary shapes: every (n_envs, n_steps) combination must give the same numbers whichever
+kernel the dispatch picks (staged: n % 64 == 0 and T >= 16; generic otherwise; T = 1 is emei_step)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _engine(*a, **k):
+    from emei_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+def _actions(env, T, N, dev, dtype=None):
+    if env.startswith("CartPole"):
+        return torch.randint(0, 2, (T, N), device=dev).to(dtype or torch.uint8)
+    if env == "HalfCheetahRunning":
+        return (torch.rand((T, N, 6), device=dev) * 2 - 1).float()
+    return (torch.rand((T, N), device=dev) * 6 - 3).float()
+
+
+@pytest.mark.parametrize("env", ["CartPoleSwingUp", "CartPoleBalancing", "ReboundInvertedPendulumSwingUp", "BoundaryInvertedPendulumBalancing"])
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000, 1024])
+@pytest.mark.parametrize("T", [1, 15, 16, 17, 48])
+def test_rollout_equals_steps_every_shape(env, N, T):
+    torch.manual_seed(N * 100 + T)
+    a = _engine(env, N, freq_rate=3, max_episode_steps=11, seed=7, init_noise=5e-3)
+    b = _engine(env, N, freq_rate=3, max_episode_steps=11, seed=7, init_noise=5e-3)
+    a.reset(7)
+    b.reset(7)
+    acts = _actions(env, T, N, a.device)
+    obs, rew, done = a.rollout(acts, auto_reset=True)
+    for t in range(T):
+        o, r, d = b.step(acts[t], auto_reset=True)
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t]), (t,)
+    assert torch.equal(a.get_state(), b.get_state())
+    assert torch.equal(a.compact_done(), torch.nonzero(done[-1]).flatten().to(torch.int32))
+    sa, ea = a.get_counters()
+    sb, eb = b.get_counters()
+    assert torch.equal(sa, sb) and torch.equal(ea, eb)
+    if T > 11:
+        assert bool((done & 2).any()) and int(ea.max()) >= 1
+
+
+@pytest.mark.parametrize("N,T", [(1, 1), (63, 5), (64, 16), (130, 17)])
+def test_cheetah_shapes(N, T):
+    torch.manual_seed(N + T)
+    a = _engine("HalfCheetahRunning", N, freq_rate=2, real_time_scale=0.002, max_episode_steps=6, seed=3, init_noise=0.1)
+    b = _engine("HalfCheetahRunning", N, freq_rate=2, real_time_scale=0.002, max_episode_steps=6, seed=3, init_noise=0.1)
+    a.reset(3)
+    b.reset(3)
+    acts = _actions("HalfCheetahRunning", T, N, a.device)
+    obs, rew, done = a.rollout(acts, auto_reset=True)
+    for t in range(T):
+        o, r, d = b.step(acts[t], auto_reset=True)
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t])
+    assert torch.equal(a.get_state(), b.get_state())
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int32, torch.int64])
+def test_action_dtypes_agree(dtype):
+    N, T = 256, 40
+    base = torch.randint(0, 2, (T, N), device="cuda")
+    outs = []
+    for dt in (torch.uint8, dtype):
+        e = _engine("CartPoleSwingUp", N, seed=1)
+        e.reset(1)
+        outs.append(e.rollout(base.to(dt).contiguous()))
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+
+
+def test_null_outputs_are_skipped():
+    """Any output pointer may be NULL (include/emei_hip.h): state still advances identically."""
+    import ctypes as C
+
+    from emei_amd import _lib as L
+    from emei_amd.engine import _ptr, _stream
+
+    N, T = 128, 32
+    a, b = _engine("CartPoleSwingUp", N, seed=2), _engine("CartPoleSwingUp", N, seed=2)
+    a.reset(2)
+    b.reset(2)
+    acts = torch.randint(0, 2, (T, N), device=a.device, dtype=torch.uint8)
+    obs, rew, done = a.rollout(acts)
+    rew_only = torch.empty((T, N), dtype=torch.float32, device=a.device)
+    L.check(L.lib().emei_rollout(b._h, T, _ptr(acts), L.ACT_U8, C.c_void_p(0), _ptr(rew_only), C.c_void_p(0), 0, _stream()))
+    assert torch.equal(rew_only, rew) and torch.equal(a.get_state(), b.get_state())
