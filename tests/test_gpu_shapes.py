@@ -40,7 +40,7 @@ def test_rollout_equals_steps_every_shape(env, N, T):
     sb, eb = b.get_counters()
     assert torch.equal(sa, sb) and torch.equal(ea, eb)
     if T > 11:
-        assert bool((done & 2).any()) and int(ea.max()) >= 1
+        assert bool((done != 0).any()) and int(ea.max()) >= 1  # TimeLimit 11 (or an earlier terminal) ended an episode
 
 
 @pytest.mark.parametrize("N,T", [(1, 1), (63, 5), (64, 16), (130, 17)])
