@@ -11,7 +11,14 @@ from . import _lib as L
 _ACT_DTYPES = {torch.uint8: L.ACT_U8, torch.int32: L.ACT_I32, torch.int64: L.ACT_I64, torch.float32: L.ACT_F32}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter avoids building a
+    Stream object on every call: 0.3 us instead of 3 us on the per-step path)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
