@@ -8,7 +8,12 @@ __version__ = "0.1.0"
 from .core import EmeiEnv, Freezable, OfflineEnv  # noqa: F401
 from .envs import (  # noqa: F401
     BaseCartPoleEnv,
+    BaseInvertedDoublePendulumEnv,
     BaseInvertedPendulumEnv,
+    BoundaryInvertedDoublePendulumBalancingEnv,
+    BoundaryInvertedDoublePendulumSwingUpEnv,
+    ReboundInvertedDoublePendulumBalancingEnv,
+    ReboundInvertedDoublePendulumSwingUpEnv,
     BoundaryInvertedPendulumBalancingEnv,
     BoundaryInvertedPendulumSwingUpEnv,
     CartPoleBalancingEnv,

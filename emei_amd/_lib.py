@@ -20,6 +20,10 @@ ENV_IDS = {
     "ReboundInvertedPendulumSwingUp": 4,
     "BoundaryInvertedPendulumSwingUp": 5,
     "HalfCheetahRunning": 6,
+    "ReboundInvertedDoublePendulumBalancing": 7,
+    "BoundaryInvertedDoublePendulumBalancing": 8,
+    "ReboundInvertedDoublePendulumSwingUp": 9,
+    "BoundaryInvertedDoublePendulumSwingUp": 10,
 }
 PRECISION_REF, PRECISION_F32 = 0, 1
 ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3

@@ -10,7 +10,7 @@
 #include <new>
 
 #include "launch.h"
-#include "cheetah.h"
+#include "body_kernels.h"
 
 using namespace emei;
 
@@ -58,6 +58,10 @@ extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, in
         case EMEI_IP_REBOUND_SWINGUP:
         case EMEI_IP_BOUNDARY_SWINGUP: od = 4, ad = 1, sd = 4; break;
         case EMEI_HALFCHEETAH_RUNNING: od = 18, ad = 6, sd = 18; break;
+        case EMEI_IDP_REBOUND_BALANCING:
+        case EMEI_IDP_BOUNDARY_BALANCING:
+        case EMEI_IDP_REBOUND_SWINGUP:
+        case EMEI_IDP_BOUNDARY_SWINGUP: od = 6, ad = 1, sd = 6; break;
         default: return fail(EMEI_ERR_INVALID, "unknown env_id %d", env_id);
     }
     if (obs_dim) *obs_dim = od;
@@ -102,6 +106,7 @@ static const void* current_device_trig() {
 }
 
 static bool is_pend(int env_id) { return env_id >= EMEI_CARTPOLE_SWINGUP && env_id <= EMEI_IP_BOUNDARY_SWINGUP; }
+static bool is_body(int env_id) { return env_id >= EMEI_HALFCHEETAH_RUNNING && env_id <= EMEI_IDP_BOUNDARY_SWINGUP; }
 
 // ---------------------------------------------------------------------------------------------
 // InvertedPendulum model constants from emei/envs/mujoco/assets/inverted_pendulum.xml
@@ -226,6 +231,25 @@ static PendLaunch pend_base(emei_env* h, void* stream) {
     return L;
 }
 
+static BodyLaunch body_base(emei_env* h, void* stream) {
+    BodyLaunch L;
+    L.env_id = h->cfg.env_id;
+    L.precision = h->cfg.precision;
+    L.state = h->state;
+    L.steps = h->steps;
+    L.episode = h->episode;
+    L.done_mask = h->done_mask;
+    L.n = h->cfg.n_envs;
+    L.freq_rate = h->cfg.freq_rate;
+    L.max_episode_steps = h->cfg.max_episode_steps;
+    L.seed = h->cfg.seed;
+    L.env_offset = h->cfg.env_index_offset;
+    L.dt = h->cfg.real_time_scale;
+    L.init_noise = h->cfg.init_noise;
+    L.stream = (hipStream_t)stream;
+    return L;
+}
+
 extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_reset: null handle");
     h->cfg.seed = seed;
@@ -235,8 +259,9 @@ extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
         L.op = PEND_OP_RESET;
         rc = pend_launch(L);
     } else {
-        rc = cheetah_reset(h->state, h->steps, h->episode, h->cfg.n_envs, h->cfg.precision, seed,
-                           h->cfg.env_index_offset, h->cfg.init_noise, (hipStream_t)stream);
+        BodyLaunch L = body_base(h, stream);
+        L.op = BODY_OP_RESET;
+        rc = body_launch(L);
     }
     if (rc != EMEI_OK) return fail(rc, "emei_reset: launch failed");
     h->has_state = true;
@@ -272,8 +297,11 @@ extern "C" EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream)
         int rc = pend_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_get_obs: launch failed");
     }
-    // HalfCheetah: obs = concat(qpos, qvel) = the state itself (mujoco_env.py:153-155)
-    return emei_get_state(h, obs_aos, stream);
+    BodyLaunch L = body_base(h, stream);
+    L.op = BODY_OP_GET_OBS;
+    L.obs_f64 = obs_aos;
+    int rc = body_launch(L);
+    return rc == EMEI_OK ? rc : fail(rc, "emei_get_obs: launch failed");
 }
 
 extern "C" EMEI_API int emei_freeze(emei_env* h, void* stream) {
@@ -331,10 +359,15 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
         L.flags = flags;
         rc = pend_launch(L);
     } else {
-        rc = cheetah_rollout(h->state, h->steps, h->episode, h->done_mask, h->cfg.n_envs, h->cfg.precision, n_steps,
-                             h->cfg.freq_rate, h->cfg.real_time_scale, h->cfg.max_episode_steps, h->cfg.seed,
-                             h->cfg.env_index_offset, h->cfg.init_noise, (const float*)actions, obs_out, reward_out,
-                             done_out, flags, (hipStream_t)stream);
+        BodyLaunch L = body_base(h, stream);
+        L.op = BODY_OP_ROLLOUT;
+        L.actions = (const float*)actions;
+        L.obs_out = obs_out;
+        L.reward_out = reward_out;
+        L.done_out = done_out;
+        L.n_steps = n_steps;
+        L.flags = flags;
+        rc = body_launch(L);
     }
     return rc == EMEI_OK ? rc : fail(rc, "emei_rollout: launch failed (%s)", hipGetErrorString(hipGetLastError()));
 }
@@ -373,8 +406,13 @@ extern "C" EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const 
         L.obs_out = obs_out;
         rc = pend_launch(L);
     } else {
-        rc = cheetah_init_obs(count, env_index, episode, h->cfg.seed, h->cfg.env_index_offset, h->cfg.init_noise, obs_out,
-                              (hipStream_t)stream);
+        BodyLaunch L = body_base(h, stream);
+        L.op = BODY_OP_INIT_OBS;
+        L.n = count;
+        L.env_index = env_index;
+        L.episode_in = episode;
+        L.obs_out = obs_out;
+        rc = body_launch(L);
     }
     return rc == EMEI_OK ? rc : fail(rc, "emei_episode_init_obs: launch failed");
 }
@@ -397,10 +435,21 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
         int rc = pend_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
     }
-    if (env_id == EMEI_HALFCHEETAH_RUNNING) {
-        if (!pre_obs || !action) return fail(EMEI_ERR_INVALID, "emei_reward: HalfCheetah needs pre_obs and action");
+    if (is_body(env_id)) {
+        if (env_id == EMEI_HALFCHEETAH_RUNNING && (!pre_obs || !action))
+            return fail(EMEI_ERR_INVALID, "emei_reward: HalfCheetah needs pre_obs and action");
         if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_reward: bad dt/freq_rate");
-        int rc = cheetah_reward(n, obs, pre_obs, action, real_time_scale * freq_rate, reward_out, (hipStream_t)stream);
+        BodyLaunch L;
+        L.op = BODY_OP_REWARD;
+        L.env_id = env_id;
+        L.precision = EMEI_PRECISION_REF;
+        L.obs_in = obs, L.pre_obs_in = pre_obs, L.actions = action;
+        L.reward_out = reward_out;
+        L.n = n;
+        L.freq_rate = freq_rate;
+        L.dt = real_time_scale;
+        L.stream = (hipStream_t)stream;
+        int rc = body_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
     }
     return fail(EMEI_ERR_INVALID, "emei_reward: unknown env_id %d", env_id);
@@ -422,8 +471,16 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
         int rc = pend_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
     }
-    if (env_id == EMEI_HALFCHEETAH_RUNNING) {
-        int rc = cheetah_terminal(n, obs, terminal_out, (hipStream_t)stream);
+    if (is_body(env_id)) {
+        BodyLaunch L;
+        L.op = BODY_OP_TERMINAL;
+        L.env_id = env_id;
+        L.precision = EMEI_PRECISION_REF;
+        L.obs_in = obs;
+        L.done_out = terminal_out;
+        L.n = n;
+        L.stream = (hipStream_t)stream;
+        int rc = body_launch(L);
         return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
     }
     return fail(EMEI_ERR_INVALID, "emei_terminal: unknown env_id %d", env_id);

@@ -1,0 +1,285 @@
+// body_kernels.h — step / rollout / reset kernels shared by the multi-DoF MuJoCo-style bodies
+// (HalfCheetah-style 9-DoF body, InvertedDoublePendulum).  A `Body` type supplies the arithmetic:
+//
+//   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
+//   struct Model;                                   // constants, passed by value as a kernel argument
+//   substep(s, ctrl, m)                             // one MuJoCo Euler substep + emei's position override
+//   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal)   // obs / reward / terminal of a finished step
+//   init(s, seed, env, episode, m)                  // device reset
+//   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
+//   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
+//
+// Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
+// observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
+// its 64 envs through a private LDS slice at every step boundary: the wave's action block
+// (64*NA contiguous floats) arrives as 16 B-per-lane loads and is read back per lane; the 64 x NO
+// observation block is written to LDS lane-wise and leaves as contiguous 16 B-per-lane stores
+// (4.5 KiB per wave and step for the cheetah).  LDS slices are wave-private: no barrier.
+#pragma once
+#include "emei_device.h"
+
+namespace emei {
+
+enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL };
+
+// host-side launch descriptor (abi.hip -> body_dispatch.hip -> body_tu.hip)
+struct BodyLaunch {
+    int op = BODY_OP_ROLLOUT, env_id = 0, precision = 0;
+    void* state = nullptr;
+    int32_t* steps = nullptr;
+    uint32_t* episode = nullptr;
+    unsigned long long* done_mask = nullptr;
+    const float* actions = nullptr;
+    const float* obs_in = nullptr;
+    const float* pre_obs_in = nullptr;
+    const int64_t* env_index = nullptr;
+    const uint32_t* episode_in = nullptr;
+    float* obs_out = nullptr;
+    double* obs_f64 = nullptr;
+    float* reward_out = nullptr;
+    uint8_t* done_out = nullptr;
+    int64_t n = 0;
+    int32_t n_steps = 1, freq_rate = 1, max_episode_steps = 0;
+    uint32_t flags = 0;
+    uint64_t seed = 0, env_offset = 0;
+    double dt = 0.002, init_noise = 0.0;
+    hipStream_t stream = nullptr;
+};
+int body_launch(const BodyLaunch& L);  // body_dispatch.hip
+
+template <class Body>
+struct BodyArgs {
+    typename Body::real* state;
+    int32_t* steps;
+    uint32_t* episode;
+    unsigned long long* done_mask;
+    const float* actions;
+    float* obs_out;
+    float* reward_out;
+    uint8_t* done_out;
+    int64_t n;
+    int32_t n_steps, freq_rate, max_episode_steps;
+    uint32_t flags;
+    uint64_t seed, env_offset;
+    typename Body::Model m;
+};
+
+// emei_step / emei_rollout (mujoco_env.py:157-167) for every env of the shard
+template <class Body>
+__global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Body> a) {
+    using R = typename Body::real;
+    constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
+    constexpr int kWaves = kBlock / kWave;
+    constexpr int kActVec = (kWave * NA + 3) / 4, kObsVec = (kWave * NO + 3) / 4;  // 16-byte vectors per wave block
+    constexpr int kActIt = (kActVec + kWave - 1) / kWave, kObsIt = (kObsVec + kWave - 1) / kWave;
+    __shared__ __attribute__((aligned(16))) float act_s[kWaves][kActIt * kWave * 4];
+    __shared__ __attribute__((aligned(16))) float obs_s[kWaves][kObsIt * kWave * 4];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t n = a.n;
+    const int64_t i0 = i - lane;                             // first env of this wave
+    const int wave_envs = (int)min((int64_t)kWave, n - i0);  // ragged last wave
+    const bool active = i < n;
+
+    R s[NS];
+    int32_t steps = 0;
+    uint32_t episode = 0;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = a.state[(int64_t)k * n + i];
+        steps = a.steps[i];
+        episode = a.episode[i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = R(0);
+    }
+    const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
+    uint32_t done = 0;
+
+    // this wave's action block of step t: wave_envs*NA contiguous floats starting at (t*n + i0)*NA
+    float4 av[kActIt];
+    auto fetch_actions = [&](int t) __attribute__((always_inline)) {
+        const float* base = a.actions + ((int64_t)t * n + i0) * NA;
+        const bool fast = wave_envs == kWave && (((uintptr_t)base) & 15u) == 0;
+#pragma unroll
+        for (int c = 0; c < kActIt; ++c) {
+            const int vec = c * kWave + lane;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fast) {
+                if (vec < kActVec) av[c] = ((const float4*)base)[vec];
+            } else {  // ragged / unaligned tail: scalar loads
+                float* f = (float*)&av[c];
+                for (int e = 0; e < 4; ++e)
+                    if (vec * 4 + e < wave_envs * NA) f[e] = base[vec * 4 + e];
+            }
+        }
+    };
+    fetch_actions(0);
+    for (int t = 0; t < a.n_steps; ++t) {
+        // stage this step's actions through LDS, then prefetch the next step's block
+#pragma unroll
+        for (int c = 0; c < kActIt; ++c) ((float4*)act_s[wv])[c * kWave + lane] = av[c];
+        wave_lds_fence();  // other lanes' vectors hold this lane's action
+        R ctrl[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) ctrl[k] = (R)act_s[wv][lane * NA + k];
+        wave_lds_fence();  // the block is consumed before the next step overwrites it
+        if (t + 1 < a.n_steps) fetch_actions(t + 1);
+
+        R pre[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) pre[k] = s[k];
+        for (int k = 0; k < a.freq_rate; ++k) Body::substep(s, ctrl, a.m);  // mujoco_env.py:88-97
+        float o[NO];
+        R rew;
+        bool term;
+        Body::outputs(s, pre, ctrl, a.m, a.freq_rate, o, rew, term);
+        ++steps;
+        const bool trunc = (a.max_episode_steps > 0) & (steps >= a.max_episode_steps);
+        done = active ? ((term ? EMEI_DONE_TERMINAL : 0u) | (trunc ? EMEI_DONE_TRUNCATED : 0u)) : 0u;
+
+        if (a.obs_out) {  // lane-wise into LDS, linear out
+            float* mine = &obs_s[wv][lane * NO];
+#pragma unroll
+            for (int k = 0; k < NO; ++k) mine[k] = o[k];
+            wave_lds_fence();
+            float* dst = a.obs_out + ((int64_t)t * n + i0) * NO;
+            if (wave_envs == kWave && (((uintptr_t)dst) & 15u) == 0) {
+#pragma unroll
+                for (int c = 0; c < kObsIt; ++c) {
+                    const int vec = c * kWave + lane;
+                    if (vec < kObsVec) ((float4*)dst)[vec] = ((const float4*)obs_s[wv])[vec];
+                }
+            } else {
+                for (int e = lane; e < wave_envs * NO; e += kWave) dst[e] = obs_s[wv][e];
+            }
+            wave_lds_fence();
+        }
+        if (active) {
+            if (a.reward_out) a.reward_out[(int64_t)t * n + i] = (float)rew;
+            if (a.done_out) a.done_out[(int64_t)t * n + i] = (uint8_t)done;
+        }
+        if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
+            if (done != 0) {
+                ++episode;
+                steps = 0;
+                Body::init(s, a.seed, a.env_offset + (uint64_t)i, episode, a.m);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) a.state[(int64_t)k * n + i] = s[k];
+        a.steps[i] = steps;
+        a.episode[i] = episode;
+    }
+    unsigned long long mk = __ballot(done != 0);
+    if (lane == 0 && active) a.done_mask[i / kWave] = mk;
+}
+
+template <class Body>
+__global__ void __launch_bounds__(kBlock)
+    body_reset_kernel(typename Body::real* state, int32_t* steps, uint32_t* episode, int64_t n, uint64_t seed,
+                      uint64_t env_offset, typename Body::Model m) {
+    using R = typename Body::real;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    R s[Body::NS];
+    Body::init(s, seed, env_offset + (uint64_t)i, 0u, m);
+#pragma unroll
+    for (int k = 0; k < Body::NS; ++k) state[(int64_t)k * n + i] = s[k];
+    steps[i] = 0;
+    episode[i] = 0;
+}
+
+// current_obs as float64 [n, NO]
+template <class Body>
+__global__ void __launch_bounds__(kBlock)
+    body_get_obs_kernel(const typename Body::real* state, double* obs, int64_t n, typename Body::Model m) {
+    using R = typename Body::real;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    R s[Body::NS];
+    double o[Body::NO];
+#pragma unroll
+    for (int k = 0; k < Body::NS; ++k) s[k] = state[(int64_t)k * n + i];
+    Body::obs_of(s, o, m);
+#pragma unroll
+    for (int k = 0; k < Body::NO; ++k) obs[i * Body::NO + k] = o[k];
+}
+
+// initial observation of (env, episode) pairs under the device reset generator
+template <class Body>
+__global__ void __launch_bounds__(kBlock)
+    body_init_obs_kernel(const int64_t* env_index, const uint32_t* episode, float* obs, int64_t count, uint64_t seed,
+                         uint64_t env_offset, typename Body::Model m) {
+    using R = typename Body::real;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    R s[Body::NS];
+    double o[Body::NO];
+    Body::init(s, seed, env_offset + (uint64_t)env_index[k], episode[k], m);
+    Body::obs_of(s, o, m);
+#pragma unroll
+    for (int j = 0; j < Body::NO; ++j) obs[k * Body::NO + j] = (float)o[j];
+}
+
+// get_batch_reward / get_batch_terminal on float32 rows
+template <class Body>
+__global__ void __launch_bounds__(kBlock)
+    body_reward_kernel(const float* obs, const float* pre_obs, const float* action, float* reward, int64_t n,
+                       int freq_rate, typename Body::Model m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    reward[i] = (float)Body::batch_reward(obs + i * Body::NO, pre_obs ? pre_obs + i * Body::NO : nullptr,
+                                          action ? action + i * Body::NA : nullptr, m, freq_rate);
+}
+template <class Body>
+__global__ void __launch_bounds__(kBlock)
+    body_terminal_kernel(const float* obs, uint8_t* terminal, int64_t n, typename Body::Model m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    terminal[i] = (uint8_t)Body::batch_terminal(obs + i * Body::NO, m);
+}
+
+// every launch of one Body type (one translation unit instantiates exactly one Body: body_tu.hip)
+template <class Body>
+static int launch_body(const BodyLaunch& L) {
+    using R = typename Body::real;
+    const typename Body::Model m = Body::make_model(L.dt, L.init_noise);
+    dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
+    switch (L.op) {
+        case BODY_OP_ROLLOUT: {
+            BodyArgs<Body> a;
+            a.state = (R*)L.state, a.steps = L.steps, a.episode = L.episode, a.done_mask = L.done_mask;
+            a.actions = L.actions, a.obs_out = L.obs_out, a.reward_out = L.reward_out, a.done_out = L.done_out;
+            a.n = L.n, a.n_steps = L.n_steps, a.freq_rate = L.freq_rate, a.max_episode_steps = L.max_episode_steps;
+            a.flags = L.flags, a.seed = L.seed, a.env_offset = L.env_offset, a.m = m;
+            hipLaunchKernelGGL(body_rollout_kernel<Body>, grid, dim3(kBlock), 0, L.stream, a);
+            break;
+        }
+        case BODY_OP_RESET:
+            hipLaunchKernelGGL(body_reset_kernel<Body>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps, L.episode,
+                               L.n, L.seed, L.env_offset, m);
+            break;
+        case BODY_OP_GET_OBS:
+            hipLaunchKernelGGL(body_get_obs_kernel<Body>, grid, dim3(kBlock), 0, L.stream, (const R*)L.state, L.obs_f64,
+                               L.n, m);
+            break;
+        case BODY_OP_INIT_OBS:
+            hipLaunchKernelGGL(body_init_obs_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.env_index, L.episode_in,
+                               L.obs_out, L.n, L.seed, L.env_offset, m);
+            break;
+        case BODY_OP_REWARD:
+            hipLaunchKernelGGL(body_reward_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.pre_obs_in,
+                               L.actions, L.reward_out, L.n, L.freq_rate, m);
+            break;
+        case BODY_OP_TERMINAL:
+            hipLaunchKernelGGL(body_terminal_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.done_out, L.n, m);
+            break;
+        default: return EMEI_ERR_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? EMEI_OK : EMEI_ERR_HIP;
+}
+
+}  // namespace emei

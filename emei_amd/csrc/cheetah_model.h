@@ -21,6 +21,9 @@
 //   * constraints (6 joint limits, 16 capsule-end/floor contact points with friction) follow the
 //     oracle exactly: one Gauss-Seidel sweep in the same fixed order.
 #pragma once
+#include <cmath>
+#include <cstring>
+
 #include "emei_device.h"
 
 namespace emei {
@@ -322,5 +325,164 @@ __device__ __forceinline__ void substep(R (&q)[NV], R (&v)[NV], const R (&ctrl)[
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// host: model constants from assets/half_cheetah.xml (inertiafromgeom, settotalmass = 14, xml:35)
+namespace cheetah_host {
+struct H2 {
+    double x, z;
+};
+inline H2 hrot(double a, H2 v) { return {v.x * std::cos(a) + v.z * std::sin(a), -v.x * std::sin(a) + v.z * std::cos(a)}; }
+inline double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
+inline double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+}  // namespace cheetah_host
+
+inline Model cheetah_make_model(double dt, double init_noise) {
+    using namespace cheetah_host;
+    Model m;
+    memset(&m, 0, sizeof(m));
+    const double r = 0.046, rho = 1000.0;
+    // bodies in the xml's order: torso, bthigh, bshin, bfoot, fthigh, fshin, ffoot
+    const int parent[7] = {-1, 0, 1, 2, 0, 4, 5};
+    const H2 bpos[7] = {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}};
+    struct G {
+        int body;
+        H2 c;
+        double ang, half;
+    } g[8] = {{0, {0, 0}, M_PI / 2, 0.5},       {0, {0.6, 0.1}, 0.87, 0.15},       {1, {0.1, -0.13}, -3.8, 0.145},
+              {2, {-0.14, -0.07}, -2.03, 0.15}, {3, {0.03, -0.097}, -0.27, 0.094}, {4, {-0.07, -0.12}, 0.52, 0.133},
+              {5, {0.065, -0.09}, -0.6, 0.106}, {6, {0.045, -0.07}, -0.6, 0.07}};
+    double gm[8], gi[8], total = 0;
+    for (int k = 0; k < 8; ++k) gm[k] = capsule_mass(rho, r, g[k].half), gi[k] = capsule_inertia_perp(rho, r, g[k].half), total += gm[k];
+    double mass[7], inertia[7];
+    H2 com[7];
+    for (int b = 0; b < 7; ++b) {
+        double mb = 0;
+        H2 c = {0, 0};
+        for (int k = 0; k < 8; ++k)
+            if (g[k].body == b) mb += gm[k], c.x += gm[k] * g[k].c.x, c.z += gm[k] * g[k].c.z;
+        c.x /= mb, c.z /= mb;
+        double I = 0;
+        for (int k = 0; k < 8; ++k)
+            if (g[k].body == b) {
+                double dx = g[k].c.x - c.x, dz = g[k].c.z - c.z;
+                I += gi[k] + gm[k] * (dx * dx + dz * dz);
+            }
+        mass[b] = mb, com[b] = c, inertia[b] = I;
+    }
+    const double s = 14.0 / total;
+    for (int b = 0; b < 7; ++b) mass[b] *= s, inertia[b] *= s;
+    // subtree masses
+    double sub[7];
+    for (int b = 0; b < 7; ++b) sub[b] = mass[b];
+    for (int b = 6; b > 0; --b) sub[parent[b]] += sub[b];
+    // permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso  <- xml body index
+    const int perm_body[7] = {3, 2, 1, 6, 5, 4, 0};
+    for (int p = 0; p < 7; ++p) {
+        const int b = perm_body[p];
+        double sx = mass[b] * com[b].x, sz = mass[b] * com[b].z;
+        double dg = inertia[b] + mass[b] * (com[b].x * com[b].x + com[b].z * com[b].z);
+        for (int c = 1; c < 7; ++c)
+            if (parent[c] == b) {
+                sx += sub[c] * bpos[c].x, sz += sub[c] * bpos[c].z;
+                dg += sub[c] * (bpos[c].x * bpos[c].x + bpos[c].z * bpos[c].z);
+            }
+        m.sx[p] = sx, m.sz[p] = sz, m.diag[p] = dg;
+    }
+    m.d_tb[0] = bpos[1].x, m.d_tb[1] = bpos[1].z;
+    m.d_tf[0] = bpos[4].x, m.d_tf[1] = bpos[4].z;
+    m.d_bt_bs[0] = bpos[2].x, m.d_bt_bs[1] = bpos[2].z;
+    m.d_bs_bf[0] = bpos[3].x, m.d_bs_bf[1] = bpos[3].z;
+    m.d_ft_fs[0] = bpos[5].x, m.d_ft_fs[1] = bpos[5].z;
+    m.d_fs_ff[0] = bpos[6].x, m.d_fs_ff[1] = bpos[6].z;
+    m.mtot = 14.0, m.gravity = 9.81, m.z0 = bpos[0].z;
+    const double stiff[6] = {240, 180, 120, 180, 120, 60}, damp[6] = {6, 4.5, 3, 4.5, 3, 1.5};
+    const double lo[6] = {-0.52, -0.785, -0.4, -1.0, -1.2, -0.5}, hi[6] = {1.05, 0.785, 0.785, 0.7, 0.87, 0.5};
+    const double gear[6] = {120, 90, 60, 120, 60, 30};
+    for (int k = 0; k < 6; ++k)
+        m.stiff[k] = stiff[k], m.damp[k] = damp[k], m.arm[k] = 0.1, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = gear[k];
+    for (int k = 0; k < 8; ++k) {  // capsule end spheres: centre -/+ half * axis, axis = +z rotated by ang about y
+        H2 ax = hrot(g[k].ang, {0, 1});
+        m.geom_end[2 * k][0] = g[k].c.x - g[k].half * ax.x, m.geom_end[2 * k][1] = g[k].c.z - g[k].half * ax.z;
+        m.geom_end[2 * k + 1][0] = g[k].c.x + g[k].half * ax.x, m.geom_end[2 * k + 1][1] = g[k].c.z + g[k].half * ax.z;
+    }
+    m.radius = r, m.friction = 0.4;
+    // solref (.02, 1) with MuJoCo's refsafe clamp timeconst >= 2 dt; solimp contacts (0,.8,.01), limits (0,.8,.03)
+    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.8;
+    m.cK = m.lK = 1.0 / (dmax * dmax * tc * tc), m.cB = m.lB = 2.0 / (dmax * tc);
+    m.c_dmin = 0.0, m.c_dmax = dmax, m.c_width = 0.01;
+    m.l_dmin = 0.0, m.l_dmax = dmax, m.l_width = 0.03;
+    m.dt = dt;
+    m.init_sigma = (float)init_noise;
+    return m;
+}
+
+
 }  // namespace cheetah
+
+// ---------------------------------------------------------------------------------------------
+// Body traits for body_kernels.h
+template <typename R>
+struct CheetahBody {
+    using real = R;
+    using Model = cheetah::Model;
+    static constexpr int NS = 18, NO = 18, NA = 6;
+    static Model make_model(double dt, double init_noise) { return cheetah::cheetah_make_model(dt, init_noise); }
+
+    __device__ __forceinline__ static void substep(R (&s)[NS], const R (&ctrl)[NA], const Model& m) {
+        R q[cheetah::NV], v[cheetah::NV];
+#pragma unroll
+        for (int k = 0; k < cheetah::NV; ++k) q[k] = s[k], v[k] = s[cheetah::NV + k];
+        cheetah::substep(q, v, ctrl, m);
+#pragma unroll
+        for (int k = 0; k < cheetah::NV; ++k) s[k] = q[k], s[cheetah::NV + k] = v[k];
+    }
+    // obs = concat(qpos, qvel) (mujoco_env.py:153-155); reward half_cheetah.py:59-63 with step() semantics
+    // (per env: w_f (x' - x)/dt_env - w_c sum a^2, dt_env = dt*freq_rate); terminal :65-67 (non-finite)
+    __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+        R cost = R(0);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);
+        rew = (s[0] - pre[0]) / ((R)m.dt * (R)freq_rate) - R(0.1) * cost;
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) fin &= finite_r(s[k]), o[k] = (float)s[k];
+        term = !fin;
+    }
+    __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) o[k] = (double)s[k];
+    }
+    // device reset: init_qpos/qvel (zeros) + sigma N(0,1) per coordinate (mujoco_env.py:137-140)
+    __device__ __forceinline__ static void init(R (&s)[NS], uint64_t seed, uint64_t env, uint32_t episode, const Model& m) {
+        float z[20];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            u32x4 r = philox4x32_10(seed, env, episode, (uint32_t)b);
+            boxmuller(r.v[0], r.v[1], z[4 * b], z[4 * b + 1]);
+            boxmuller(r.v[2], r.v[3], z[4 * b + 2], z[4 * b + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = (R)__fmul_rn(m.init_sigma, z[i]);
+    }
+    // half_cheetah.py:59-63 for one row (the reference's batch form sums np.square(action) over the WHOLE
+    // batch, a quirk documented in DESIGN.md); float32 in, float64 arithmetic
+    __device__ __forceinline__ static double batch_reward(const float* obs, const float* pre_obs, const float* act,
+                                                          const Model& m, int freq_rate) {
+        double cost = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
+        return ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - 0.1 * cost;
+    }
+    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model&) {
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) fin &= finite_r(obs[k]);
+        return !fin;
+    }
+};
+
 }  // namespace emei

@@ -1,0 +1,200 @@
+// dpend_model.h — InvertedDoublePendulum (emei/envs/mujoco/inverted_double_pendulum.py on
+// mujoco_env.py; model emei/envs/mujoco/assets/inverted_double_pendulum.xml): cart on a rail + two
+// hinged poles, 3 DoF.  VARIANT 0 ReboundBalancing (:63-90), 1 BoundaryBalancing (:93-123),
+// 2 ReboundSwingUp (:126-153), 3 BoundarySwingUp (:156-196).
+//
+// Same absolute-angle formulation as cheetah_model.h (M[x,phi_j] = S_j.z, M[phi_1,phi_2] = D.S_2,
+// constant diagonals, centripetal terms Omega_j^2 * rotated vectors), restated independently by the
+// oracle (oracle/dpend_oracle.c: joint-coordinate Jacobians).  Parity with libmujoco is unpinned.
+// Reference quirks reproduced on purpose: the observation "wrap" is ((theta+pi) % 2) * pi - pi
+// (operator precedence, :59) and reward/terminal are evaluated on those wrapped values, as step()
+// does (mujoco_env.py:160-163); gravity has an x component of 1e-5 (xml:26).
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "emei_device.h"
+
+namespace emei {
+namespace dpend {
+
+struct Model {
+    double s1z, s2z, diag1, diag2, L1, mtot;  // mass-moment z of each pole, constant inertias, pole-1 length
+    double gx, gz, gear, x_lo, x_hi, margin, invw;
+    double K, B, dmin, dmax, width;  // slider-limit solref (refsafe'd) / solimp
+    double dt, phi_off;
+    float init_sigma;
+};
+
+namespace host {
+inline double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
+inline double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+}  // namespace host
+
+inline Model make_model(bool swingup, double dt, double init_noise) {
+    Model m;
+    memset(&m, 0, sizeof(m));
+    const double rho = 1000.0;
+    const double mc = host::capsule_mass(rho, 0.1, 0.1);                      // cart capsule, xml:32
+    const double mp = host::capsule_mass(rho, 0.045, 0.3);                    // each pole: fromto 0..0.6, r .045 (xml:35,38)
+    const double Ip = host::capsule_inertia_perp(rho, 0.045, 0.3);
+    const double lc = 0.3, L1 = 0.6;                                          // pole com, pole-2 attachment (xml:36)
+    m.s1z = mp * lc + mp * L1, m.s2z = mp * lc;
+    m.diag1 = Ip + mp * lc * lc + mp * L1 * L1, m.diag2 = Ip + mp * lc * lc;
+    m.L1 = L1, m.mtot = mc + 2 * mp;
+    m.gx = 1e-5, m.gz = 9.81;                                                 // gravity "1e-5 0 -9.81" (xml:26)
+    m.gear = 500.0;                                                           // xml:45, ctrlrange +-1
+    m.x_lo = -3.0, m.x_hi = 3.0, m.margin = 0.01;                             // xml:31
+    // dof_invweight0 of the slider: (M^-1)_xx at qpos0 (both poles upright)
+    const double a = m.mtot, b = m.s1z, c = m.s2z, d = m.diag1, e = L1 * m.s2z, f = m.diag2;
+    const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
+    m.invw = (d * f - e * e) / det;
+    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.95;             // default solref (.02 1), solimp (.9 .95 .001)
+    m.K = 1.0 / (dmax * dmax * tc * tc), m.B = 2.0 / (dmax * tc);
+    m.dmin = 0.9, m.dmax = dmax, m.width = 0.001;
+    m.dt = dt;
+    m.phi_off = swingup ? M_PI : 0.0;                                         // _update_model: body_quat[2] = (0,0,1,0)
+    m.init_sigma = (float)init_noise;
+    return m;
+}
+
+}  // namespace dpend
+
+template <int VARIANT, typename R>
+struct DPendBody {
+    using real = R;
+    using Model = dpend::Model;
+    static constexpr int NS = 6, NO = 6, NA = 1;
+    static Model make_model(double dt, double init_noise) { return dpend::make_model(VARIANT >= 2, dt, init_noise); }
+
+    // state s = (x, theta1, theta2, v, omega1, omega2)
+    __device__ __forceinline__ static void substep(R (&s)[NS], const R (&ctrl)[NA], const Model& m) {
+        const R phi1 = s[1] + (R)m.phi_off, phi2 = phi1 + s[2];
+        const R w1 = s[4], w2 = s[4] + s[5];
+        R s1, c1, s2, c2;
+        sincos_r(phi1, s1, c1);
+        sincos_r(phi2, s2, c2);
+        // S_j = R(phi_j)(0, s_jz) = (s_jz sin, s_jz cos);  D = R(phi_1)(0, L1)
+        const R S1x = (R)m.s1z * s1, S1z = (R)m.s1z * c1, S2x = (R)m.s2z * s2, S2z = (R)m.s2z * c2;
+        const R Dx = (R)m.L1 * s1, Dz = (R)m.L1 * c1;
+        const R M12 = fma_r(Dx, S2x, Dz * S2z);  // D . S2
+        const R u = ctrl[0] < R(-1) ? R(-1) : (ctrl[0] > R(1) ? R(1) : ctrl[0]);
+        const R w1s = w1 * w1, w2s = w2 * w2;
+        R fx = (R)m.gear * u + (R)m.mtot * (R)m.gx + w1s * S1x + w2s * S2x;
+        R f1 = (R)m.gx * S1z + (R)m.gz * S1x + w2s * fma_r(S2x, Dz, -(S2z * Dx));  // S2 . perp(D)
+        R f2 = (R)m.gx * S2z + (R)m.gz * S2x + w1s * fma_r(Dx, S2z, -(Dz * S2x));  // D . perp(S2)
+        // symmetric 3x3 [[a b c],[b d e],[c e f]] in the order (x, phi1, phi2): LDL^T eliminating phi2, phi1, x
+        const R a = (R)m.mtot, b = S1z, c = S2z, d = (R)m.diag1, e = M12, f = (R)m.diag2;
+        const R if_ = rcp_r(f);
+        const R le = e * if_, lc = c * if_;          // column of phi2
+        const R d1 = fma_r(-le, e, d), b1 = fma_r(-le, c, b), a1 = fma_r(-lc, c, a);
+        const R id1 = rcp_r(d1);
+        const R lb = b1 * id1;
+        const R a2 = fma_r(-lb, b1, a1);
+        const R ia2 = rcp_r(a2);
+        // solve M acc = rhs for rhs = (fx, f1, f2) and, when the limit is active, rhs = e_x
+        auto solve = [&](R rx, R r1, R r2, R& ox, R& o1, R& o2) __attribute__((always_inline)) {
+            R y1 = fma_r(-le, r2, r1);                  // forward: phi2 -> phi1, x
+            R yx = fma_r(-lc, r2, rx);
+            yx = fma_r(-lb, y1, yx);
+            ox = yx * ia2;                              // back substitution
+            o1 = fma_r(-lb, ox, y1 * id1);
+            o2 = fma_r(-le, o1, fma_r(-lc, ox, r2 * if_));
+        };
+        R ax, a1_, a2_;
+        solve(fx, f1, f2, ax, a1_, a2_);
+        // soft slider limit with margin 0.01 (mjCNSTR_LIMIT_JOINT: active when dist < margin)
+        R dist = R(0), J = R(0);
+        if (s[0] - (R)m.x_lo < (R)m.margin) dist = s[0] - (R)m.x_lo, J = R(1);
+        else if ((R)m.x_hi - s[0] < (R)m.margin) dist = (R)m.x_hi - s[0], J = R(-1);
+        if (J != R(0)) {
+            R wx, w1_, w2_;
+            solve(R(1), R(0), R(0), wx, w1_, w2_);
+            const R pos = dist - (R)m.margin;
+            const R xx = fabs(pos) / (R)m.width;
+            const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
+            const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);
+            const R aref = -(R)m.B * (J * s[3]) - (R)m.K * imp * pos;
+            const R Rr = (R(1) - imp) / imp * (R)m.invw;
+            const R force = (aref - J * ax) / (wx + Rr);
+            if (force > R(0)) {
+                ax = fma_r(wx, J * force, ax);
+                a1_ = fma_r(w1_, J * force, a1_);
+                a2_ = fma_r(w2_, J * force, a2_);
+            }
+        }
+        const R dt = (R)m.dt;
+        s[0] = fma_r(dt, s[3], s[0]);  // get_euler_pos (mujoco_env.py:189-191): old velocities
+        s[1] = fma_r(dt, s[4], s[1]);
+        s[2] = fma_r(dt, s[5], s[2]);
+        s[3] = fma_r(dt, ax, s[3]);
+        s[4] = fma_r(dt, a1_, s[4]);
+        s[5] = fma_r(dt, a2_ - a1_, s[5]);  // theta2'' = Omega2' - Omega1'
+    }
+
+    // inverted_double_pendulum.py:57-60: state[1:3] = (state[1:3] + pi) % 2 * pi - pi   (sic)
+    template <typename T>
+    __device__ __forceinline__ static T quirk_wrap(T th) {
+        const T pi = T(3.141592653589793);
+        return pymod_pos(th + pi, T(2), T(0.5)) * pi - pi;
+    }
+    template <typename T>
+    __device__ __forceinline__ static void reward_terminal(const T (&o)[NO], const Model& m, T& rew, bool& term) {
+        T sa, ca, sb, cb;
+        sincos_r(o[1], sa, ca);
+        sincos_r(o[1] + o[2], sb, cb);
+        const T y = ca + cb;
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) fin &= finite_r(o[k]);
+        const bool inx = ((T)m.x_lo < o[0]) & (o[0] < (T)m.x_hi);
+        if (VARIANT == 0) rew = T(1), term = !((y >= T(1.5)) & fin);            // :84-90
+        else if (VARIANT == 1) rew = T(1), term = !((y >= T(0)) & inx & fin);   // :114-123
+        else if (VARIANT == 2) rew = (T(2) - y) / T(4), term = !fin;            // :144-153
+        else rew = (T(2) - y) / T(4) - (T(5e-3) * o[4] * o[4] + T(1e-4) * o[5] * o[5]), term = !(inx & fin);  // :183-196
+    }
+    __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+        R ob[NO] = {s[0], quirk_wrap(s[1]), quirk_wrap(s[2]), s[3], s[4], s[5]};
+        reward_terminal(ob, m, rew, term);
+#pragma unroll
+        for (int k = 0; k < NO; ++k) o[k] = (float)ob[k];
+    }
+    __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
+        o[0] = (double)s[0], o[1] = (double)quirk_wrap(s[1]), o[2] = (double)quirk_wrap(s[2]);
+        o[3] = (double)s[3], o[4] = (double)s[4], o[5] = (double)s[5];
+    }
+    // device reset: zeros + sigma N(0,1) per coordinate (mujoco_env.py:137-140)
+    __device__ __forceinline__ static void init(R (&s)[NS], uint64_t seed, uint64_t env, uint32_t episode, const Model& m) {
+        float z[8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u32x4 r = philox4x32_10(seed, env, episode, (uint32_t)b);
+            boxmuller(r.v[0], r.v[1], z[4 * b], z[4 * b + 1]);
+            boxmuller(r.v[2], r.v[3], z[4 * b + 2], z[4 * b + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = (R)__fmul_rn(m.init_sigma, z[i]);
+    }
+    __device__ __forceinline__ static double batch_reward(const float* obs, const float*, const float*, const Model& m, int) {
+        double o[NO], rew;
+        bool term;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
+        reward_terminal(o, m, rew, term);
+        return rew;
+    }
+    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
+        double o[NO], rew;
+        bool term;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
+        reward_terminal(o, m, rew, term);
+        return term;
+    }
+};
+
+}  // namespace emei

@@ -12,6 +12,19 @@ constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------------------------
+// Lanes of ONE wave exchanging data through their private LDS slice need no s_barrier (a wave's LDS
+// operations execute in order), but the COMPILER must not move a lane's read above another lane's
+// write: per-thread alias analysis sees "this thread wrote bytes [16l,16l+16) and reads [4l,4l+4)" as
+// disjoint and may hoist the read (it did, in the float32 build of the body kernel).  A
+// wavefront-scope release/acquire pair around a wave barrier pins the order; it costs at most an
+// s_waitcnt lgkmcnt(0).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
 // trigonometry in the precision of the env.  Fast path: emei_math.h (straight-line, ~35 instructions);
 // the device library's Payne-Hanek sincos only repairs the (practically unreachable) |x| > 1e6 case,
 // AFTER the straight-line code, so that the hot basic block is not split.

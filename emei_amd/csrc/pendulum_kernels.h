@@ -261,8 +261,10 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
                 rew_s[wv][q][lane] = (float)rew;
                 done_s[wv][j][lane] = (uint8_t)done;
                 if (q == 3) {
+                    wave_lds_fence();  // the flush reads what OTHER lanes staged
                     rew_pend = ((const float4*)&rew_s[wv][0][0])[lane];                             // 4 rows x 256 B
                     if (g == kStage / 4 - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];  // 16 rows x 64 B
+                    wave_lds_fence();  // ... and is done before the next group overwrites the slice
                 }
                 maybe_reset();
             }

@@ -1,5 +1,12 @@
 from .cartpole import BaseCartPoleEnv, CartPoleBalancingEnv, CartPoleSwingUpEnv
 from .half_cheetah import HalfCheetahRunningEnv
+from .inverted_double_pendulum import (
+    BaseInvertedDoublePendulumEnv,
+    BoundaryInvertedDoublePendulumBalancingEnv,
+    BoundaryInvertedDoublePendulumSwingUpEnv,
+    ReboundInvertedDoublePendulumBalancingEnv,
+    ReboundInvertedDoublePendulumSwingUpEnv,
+)
 from .inverted_pendulum import (
     BaseInvertedPendulumEnv,
     BoundaryInvertedPendulumBalancingEnv,

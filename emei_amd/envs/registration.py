@@ -5,6 +5,12 @@ reference registers (``max_episode_steps``), realised on the device as the `trun
 """
 from .cartpole import CartPoleBalancingEnv, CartPoleSwingUpEnv
 from .half_cheetah import HalfCheetahRunningEnv
+from .inverted_double_pendulum import (
+    BoundaryInvertedDoublePendulumBalancingEnv,
+    BoundaryInvertedDoublePendulumSwingUpEnv,
+    ReboundInvertedDoublePendulumBalancingEnv,
+    ReboundInvertedDoublePendulumSwingUpEnv,
+)
 from .inverted_pendulum import (
     BoundaryInvertedPendulumBalancingEnv,
     BoundaryInvertedPendulumSwingUpEnv,
@@ -12,7 +18,7 @@ from .inverted_pendulum import (
     ReboundInvertedPendulumSwingUpEnv,
 )
 
-# id: (class, max_episode_steps)   register_env.py:14-23, 47-66, 102-106
+# id: (class, max_episode_steps)   register_env.py:14-23, 47-86, 102-106
 REGISTRY = {
     "CartPoleBalancing-v0": (CartPoleBalancingEnv, 500),
     "CartPoleSwingUp-v0": (CartPoleSwingUpEnv, 1000),
@@ -20,6 +26,10 @@ REGISTRY = {
     "ReboundInvertedPendulumBalancing-v0": (ReboundInvertedPendulumBalancingEnv, 1000),
     "BoundaryInvertedPendulumSwingUp-v0": (BoundaryInvertedPendulumSwingUpEnv, 1000),
     "BoundaryInvertedPendulumBalancing-v0": (BoundaryInvertedPendulumBalancingEnv, 1000),
+    "ReboundInvertedDoublePendulumSwingUp-v0": (ReboundInvertedDoublePendulumSwingUpEnv, 1000),
+    "ReboundInvertedDoublePendulumBalancing-v0": (ReboundInvertedDoublePendulumBalancingEnv, 1000),
+    "BoundaryInvertedDoublePendulumSwingUp-v0": (BoundaryInvertedDoublePendulumSwingUpEnv, 1000),
+    "BoundaryInvertedDoublePendulumBalancing-v0": (BoundaryInvertedDoublePendulumBalancingEnv, 1000),
     "HalfCheetahRunning-v0": (HalfCheetahRunningEnv, 1000),
 }
 

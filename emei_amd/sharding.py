@@ -46,6 +46,8 @@ def synthetic_init_state(env, n_global, lo, hi, seed=0):
         if env == "CartPoleSwingUp":
             s[:, 2] += np.pi
         return s[lo:hi]
+    if "InvertedDoublePendulum" in env:
+        return (rng.standard_normal((n_global, 6)) * 5e-3)[lo:hi]
     if "InvertedPendulum" in env:
         return (rng.standard_normal((n_global, 4)) * 5e-3)[lo:hi]  # mujoco_env.py:31,137-140
     if env == "HalfCheetahRunning":
@@ -58,7 +60,7 @@ def synthetic_actions(env, horizon, n, rank, world, device, act_dim):
     rng = np.random.default_rng(1 if world == 1 else [1, rank])
     if env.startswith("CartPole"):
         return torch.as_tensor(rng.integers(2, size=(horizon, n), dtype=np.uint8), device=device)
-    lim = 3.0 if "InvertedPendulum" in env else 1.0
+    lim = 3.0 if ("InvertedPendulum" in env and "Double" not in env) else 1.0
     shape = (horizon, n) if act_dim <= 1 else (horizon, n, act_dim)
     return torch.as_tensor(rng.uniform(-lim, lim, size=shape).astype(np.float32), device=device)
 
@@ -84,7 +86,7 @@ class ShardedRollout:
         self.seed = seed
         self.actions = self.out = self.gathered = None
         self._events = []
-        self.kernel_name = "pend_rollout_staged_kernel" if env != "HalfCheetahRunning" else "cheetah_rollout_kernel"
+        self.kernel_name = "body_rollout_kernel" if (env == "HalfCheetahRunning" or "Double" in env) else "pend_rollout_staged_kernel"
 
     @property
     def action_bytes(self):

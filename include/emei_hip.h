@@ -37,7 +37,11 @@ enum emei_env_id {
     EMEI_IP_REBOUND_SWINGUP = 4,    /* emei/envs/mujoco/inverted_pendulum.py:114-146 */
     EMEI_IP_BOUNDARY_SWINGUP = 5,   /* emei/envs/mujoco/inverted_pendulum.py:149-183 */
     EMEI_HALFCHEETAH_RUNNING = 6,   /* emei/envs/mujoco/half_cheetah.py:16-67        */
-    EMEI_NUM_ENVS_IDS = 7
+    EMEI_IDP_REBOUND_BALANCING = 7,  /* emei/envs/mujoco/inverted_double_pendulum.py:63-90   */
+    EMEI_IDP_BOUNDARY_BALANCING = 8, /* emei/envs/mujoco/inverted_double_pendulum.py:93-123  */
+    EMEI_IDP_REBOUND_SWINGUP = 9,    /* emei/envs/mujoco/inverted_double_pendulum.py:126-153 */
+    EMEI_IDP_BOUNDARY_SWINGUP = 10,  /* emei/envs/mujoco/inverted_double_pendulum.py:156-196 */
+    EMEI_NUM_ENVS_IDS = 11
 };
 
 /* Arithmetic the kernels compute in.

@@ -139,9 +139,10 @@ def import_reference(ref_root):
     from emei.envs.mujoco import inverted_pendulum as ip
     from emei.envs.mujoco import half_cheetah as hc
     from emei.envs.mujoco import mujoco_env as me
+    from emei.envs.mujoco import inverted_double_pendulum as idp
     from emei import core
 
-    return NS(cp=cp, ip=ip, hc=hc, me=me, core=core)
+    return NS(cp=cp, ip=ip, hc=hc, me=me, core=core, idp=idp)
 
 
 # --------------------------------------------------------------------------- inputs
@@ -388,6 +389,45 @@ def gen_mujoco_firstparty(ref, out):
     return data
 
 
+def gen_dpend_firstparty(ref, out):
+    """InvertedDoublePendulum: the four reward/terminal functions and the (quirky) observation wrap,
+    called unbound on a stand-in self (slider range from assets/inverted_double_pendulum.xml:31)."""
+    data = {}
+    rng = np.random.default_rng(4242)
+    idp = ref.idp
+    fake = NS(model=NS(jnt_range=np.array([[-3.0, 3.0], [0.0, 0.0], [0.0, 0.0]])))
+    B = 512
+    obs = np.empty((B, 6))
+    obs[:, 0] = rng.uniform(-3.5, 3.5, B)
+    obs[:, 1:3] = rng.uniform(-math.pi, math.pi, (B, 2))
+    obs[:, 3:] = rng.normal(0, 4, (B, 3))
+    obs[: B // 4, 1:3] = rng.normal(0, 0.3, (B // 4, 2))  # near upright: y close to the 1.5 / 0 thresholds
+    obs[0, 0], obs[1, 0] = 3.0, -3.0
+    obs[2, 0], obs[3, 0] = np.nextafter(3.0, 0.0), np.nextafter(-3.0, 0.0)
+    obs[4] = [0.0, np.nan, 0.0, 0.0, 0.0, 0.0]
+    obs[5] = [0.0, 0.0, 0.0, 0.0, np.inf, 0.0]
+    obs[6] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    data["dp_obs"] = obs
+    with np.errstate(all="ignore"):
+        for nm, cls in (
+            ("rebound_balancing", idp.ReboundInvertedDoublePendulumBalancingEnv),
+            ("boundary_balancing", idp.BoundaryInvertedDoublePendulumBalancingEnv),
+            ("rebound_swingup", idp.ReboundInvertedDoublePendulumSwingUpEnv),
+            ("boundary_swingup", idp.BoundaryInvertedDoublePendulumSwingUpEnv),
+        ):
+            data[f"dp_{nm}_reward"] = np.asarray(cls.get_batch_reward(fake, obs), dtype=np.float64)
+            data[f"dp_{nm}_terminal"] = cls.get_batch_terminal(fake, obs)
+    sv = np.column_stack([rng.uniform(-3, 3, 256), rng.uniform(-30, 30, 256), rng.uniform(-30, 30, 256), rng.normal(0, 3, (256, 3))])
+    sv[0, 1:3] = [0.0, math.pi]
+    wrapped = np.empty_like(sv)
+    for i in range(len(sv)):
+        wrapped[i] = idp.BaseInvertedDoublePendulumEnv.current_obs.fget(NS(state_vector=lambda i=i: sv[i]))
+    data["dp_wrap_in"] = sv
+    data["dp_wrap_out"] = wrapped
+    np.savez_compressed(os.path.join(out, "dpend_firstparty_golden.npz"), **data)
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -397,12 +437,13 @@ def main():
     ref = import_reference(a.ref)
     c = gen_cartpole(ref, a.out)
     m = gen_mujoco_firstparty(ref, a.out)
+    d = gen_dpend_firstparty(ref, a.out)
     env = ref.cp.CartPoleSwingUpEnv()
     o, _ = env.reset(seed=0)
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m))
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d))
 
 
 if __name__ == "__main__":

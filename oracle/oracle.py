@@ -20,7 +20,7 @@ IP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup
 
 def build(force=False):
     """Compile the oracle with gcc (no GPU needed)."""
-    srcs = [os.path.join(_HERE, f) for f in ("emei_oracle.c", "cheetah_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("emei_oracle.c", "cheetah_oracle.c", "dpend_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
@@ -238,3 +238,42 @@ def cheetah_inertia(q, v):
     e = C.c_double()
     lib().cheetah_oracle_inertia(_p(q, C.c_double), _p(v, C.c_double), _p(M, C.c_double), _p(b, C.c_double), C.byref(e))
     return M, b, e.value
+
+
+# --------------------------------------------------------------------------- InvertedDoublePendulum (C)
+DP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup": 2, "boundary_swingup": 3}
+
+
+def dpend_step(variant, state, action, freq_rate=1, dt=0.02):
+    """state [n,6] = (x, th1, th2, v, w1, w2) float64 -> (next_state, obs (quirk-wrapped), reward, terminal)."""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 6)
+    n = st.shape[0]
+    act = np.ascontiguousarray(action, dtype=np.float64).reshape(n)
+    obs = np.empty((n, 6))
+    rew = np.empty(n)
+    term = np.empty(n, np.uint8)
+    lib().dpend_oracle_step(C.c_int(DP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+                            _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    return st, obs, rew, term.astype(bool)
+
+
+def dpend_reward_terminal(variant, obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 6)
+    rew = np.empty(len(obs))
+    term = np.empty(len(obs), np.uint8)
+    lib().dpend_oracle_reward_terminal(C.c_int(DP_VARIANTS[variant]), C.c_int64(len(obs)), _p(obs, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    return rew, term.astype(bool)
+
+
+def dpend_wrap(theta):
+    th = np.ascontiguousarray(theta, np.float64).reshape(-1)
+    out = np.empty_like(th)
+    lib().dpend_oracle_wrap(C.c_int64(len(th)), _p(th, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def dpend_energy(variant, state):
+    s = np.ascontiguousarray(state, np.float64).reshape(6)
+    f = lib().dpend_oracle_energy
+    f.restype = C.c_double
+    return f(C.c_int(DP_VARIANTS[variant]), _p(s, C.c_double))
