@@ -122,6 +122,35 @@ class Engine:
                                      L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
 
+    def capture_step_graph(self, actions, auto_reset=False):
+        """Capture one emei_step launch per row of `actions` [K, N(,act_dim)] into a hipGraph.
+
+        For callers that need a launch per env-step (e.g. a policy evaluated between steps is captured
+        alongside) the graph removes the per-launch host cost (6.7 -> 3.7 us per step at 65 536 envs).
+        The ABI's launch functions neither allocate nor synchronise, so they are capturable as they
+        are.  Returns (graph, obs [K,N,obs_dim], reward [K,N], done [K,N]); `actions` and the outputs are
+        the graph's static buffers: refill `actions` in place, then `graph.replay()`."""
+        K = int(actions.shape[0])
+        dt = self._check_actions(actions, (K,))
+        obs, rew, done = self.alloc_outputs(K)
+        flags = L.FLAG_AUTO_RESET if auto_reset else 0
+        lib = L.lib()
+
+        def launch_all():
+            st = _stream()
+            for k in range(K):
+                L.check(lib.emei_step(self._h, _ptr(actions[k]), dt, _ptr(obs[k]), _ptr(rew[k]), _ptr(done[k]), flags, st))
+
+        if not self.get_state().isfinite().any():  # touches the state: also asserts reset() happened
+            raise L.EmeiHipError("capture_step_graph: state has no finite entry")
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            launch_all()
+        torch.cuda.current_stream().wait_stream(side)
+        return graph, obs, rew, done
+
     def alloc_outputs(self, n_steps=None):
         lead = () if n_steps is None else (int(n_steps),)
         return (torch.empty(lead + (self.n_envs, self.obs_dim), dtype=torch.float32, device=self.device),

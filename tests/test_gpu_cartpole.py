@@ -269,3 +269,21 @@ def test_full_size_properties():
     x = obs[..., 0].abs()
     clear = (x - 5.0).abs() > 1e-4
     assert torch.equal(((done & 1) != 0)[clear], (x >= 5.0)[clear])
+
+
+def test_step_launches_are_graph_capturable():
+    """The ABI launch functions neither allocate nor synchronise: K per-step launches captured into one
+    hipGraph replay to exactly the fused rollout's results, and keep advancing the state on each replay."""
+    N, K = 4096, 24
+    a = _engine("CartPoleSwingUp", N, max_episode_steps=10, seed=6)
+    b = _engine("CartPoleSwingUp", N, max_episode_steps=10, seed=6)
+    a.reset(6)
+    b.reset(6)
+    acts = torch.randint(0, 2, (K, N), device=a.device, dtype=torch.uint8)
+    graph, obs, rew, done = a.capture_step_graph(acts, auto_reset=True)  # capture does not execute the launches
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        r_obs, r_rew, r_done = b.rollout(acts, auto_reset=True)
+        assert torch.equal(obs, r_obs) and torch.equal(rew, r_rew) and torch.equal(done, r_done)
+    assert torch.equal(a.get_state(), b.get_state())
