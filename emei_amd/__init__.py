@@ -19,6 +19,7 @@ from .envs import (  # noqa: F401
     CartPoleBalancingEnv,
     CartPoleSwingUpEnv,
     HalfCheetahRunningEnv,
+    HopperRunningEnv,
     ReboundInvertedPendulumBalancingEnv,
     ReboundInvertedPendulumSwingUpEnv,
     make,

@@ -24,13 +24,19 @@ ENV_IDS = {
     "BoundaryInvertedDoublePendulumBalancing": 8,
     "ReboundInvertedDoublePendulumSwingUp": 9,
     "BoundaryInvertedDoublePendulumSwingUp": 10,
+    "HopperRunning": 11,
 }
 PRECISION_REF, PRECISION_F32 = 0, 1
 ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
 FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
-ABI_VERSION = 1
+ABI_VERSION = 2
+# enum emei_integrator (mujoco_env.py:70-79) / enum emei_noise_layout
+INTEGRATORS = {"euler": 0, "semi_implicit_euler": 1, "rk4": 2}
+NOISE_IID, NOISE_SHARED = 0, 1
+CONFIG_SIZE_V1 = 64
+MAX_STATE_DIM = 32
 
 
 class EmeiConfig(C.Structure):
@@ -48,6 +54,11 @@ class EmeiConfig(C.Structure):
         ("seed", C.c_uint64),
         ("env_index_offset", C.c_uint64),
         ("init_noise", C.c_double),
+        # ABI version 2
+        ("integrator", C.c_int32),
+        ("noise_layout", C.c_int32),
+        ("init_sigma", C.c_float * MAX_STATE_DIM),
+        ("obs_sigma", C.c_float * MAX_STATE_DIM),
     ]
 
 

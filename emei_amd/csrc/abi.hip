@@ -62,6 +62,7 @@ extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, in
         case EMEI_IDP_BOUNDARY_BALANCING:
         case EMEI_IDP_REBOUND_SWINGUP:
         case EMEI_IDP_BOUNDARY_SWINGUP: od = 6, ad = 1, sd = 6; break;
+        case EMEI_HOPPER_RUNNING: od = 12, ad = 3, sd = 12; break;
         default: return fail(EMEI_ERR_INVALID, "unknown env_id %d", env_id);
     }
     if (obs_dim) *obs_dim = od;
@@ -106,7 +107,17 @@ static const void* current_device_trig() {
 }
 
 static bool is_pend(int env_id) { return env_id >= EMEI_CARTPOLE_SWINGUP && env_id <= EMEI_IP_BOUNDARY_SWINGUP; }
-static bool is_body(int env_id) { return env_id >= EMEI_HALFCHEETAH_RUNNING && env_id <= EMEI_IDP_BOUNDARY_SWINGUP; }
+static bool is_ip(int env_id) { return env_id >= EMEI_IP_REBOUND_BALANCING && env_id <= EMEI_IP_BOUNDARY_SWINGUP; }
+// The classic-control envs ignore `integrator` like the reference (base_control.py:73) and have no
+// observation noise; an InvertedPendulum with a non-default integrator or observation noise leaves
+// the staged 4-state kernel for the generic Body rollout (ipend_model.h).
+static bool steps_as_body(const emei_config& c) {
+    if (!is_pend(c.env_id)) return true;
+    bool obs_noise = false;
+    for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i) obs_noise |= c.obs_sigma[i] != 0.f;
+    return is_ip(c.env_id) && (c.integrator != EMEI_INTEG_EULER || obs_noise);
+}
+static bool is_body(int env_id) { return env_id >= EMEI_HALFCHEETAH_RUNNING && env_id <= EMEI_HOPPER_RUNNING; }
 
 // ---------------------------------------------------------------------------------------------
 // InvertedPendulum model constants from emei/envs/mujoco/assets/inverted_pendulum.xml
@@ -120,12 +131,13 @@ static double capsule_inertia_perp(double rho, double r, double half) {
     return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
 }
 
-static PendParams pend_params(int env_id, double dt, double init_noise) {
+static PendParams pend_params(int env_id, double dt, const float* init_sigma = nullptr, int noise_shared = 0) {
     PendParams p;
     memset(&p, 0, sizeof(p));
     p.dt = dt;
     p.dt32 = (float)dt;
-    p.init_sigma = (float)init_noise;
+    for (int i = 0; i < 4; ++i) p.init_sigma[i] = init_sigma ? init_sigma[i] : 0.f;
+    p.noise_shared = noise_shared;
     const double rho = 1000.0, g = 9.81;
     double mc = capsule_mass(rho, 0.1, 0.1);
     double fx = 0.001, fz = 0.6, len = std::sqrt(fx * fx + fz * fz);
@@ -152,9 +164,23 @@ static PendParams pend_params(int env_id, double dt, double init_noise) {
 // ---------------------------------------------------------------------------------------------
 extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (!cfg || !out) return fail(EMEI_ERR_INVALID, "emei_create: null argument");
-    if (cfg->struct_size != sizeof(emei_config))
-        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu", cfg->struct_size,
-                    sizeof(emei_config));
+    if (cfg->struct_size != sizeof(emei_config) && cfg->struct_size != EMEI_CONFIG_SIZE_V1)
+        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu (or the version-1 size %u)",
+                    cfg->struct_size, sizeof(emei_config), EMEI_CONFIG_SIZE_V1);
+    emei_config c2;  // the caller's struct, widened to this library's layout
+    memset(&c2, 0, sizeof(c2));
+    memcpy(&c2, cfg, cfg->struct_size);
+    if (cfg->struct_size == EMEI_CONFIG_SIZE_V1)
+        for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i) c2.init_sigma[i] = (float)c2.init_noise;
+    c2.struct_size = sizeof(emei_config);
+    cfg = &c2;
+    if (cfg->integrator < EMEI_INTEG_EULER || cfg->integrator > EMEI_INTEG_RK4)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_create: integrator=%d", cfg->integrator);  // mujoco_env.py:78-79
+    if (cfg->noise_layout != EMEI_NOISE_IID && cfg->noise_layout != EMEI_NOISE_SHARED)
+        return fail(EMEI_ERR_INVALID, "emei_create: noise_layout=%d", cfg->noise_layout);
+    for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i)
+        if (!(cfg->init_sigma[i] >= 0) || !(cfg->obs_sigma[i] >= 0))
+            return fail(EMEI_ERR_INVALID, "emei_create: noise sigmas must be >= 0");
     int od, ad, sd;
     if (emei_env_dims(cfg->env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
     if (cfg->n_envs <= 0 || cfg->n_envs > (int64_t)1 << 31)
@@ -189,7 +215,8 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
         emei_destroy(h);
         return fail(EMEI_ERR_HIP, "emei_create: allocation failed: %s", hipGetErrorString(e));
     }
-    if (is_pend(cfg->env_id)) h->pend = pend_params(cfg->env_id, cfg->real_time_scale, cfg->init_noise);
+    if (is_pend(cfg->env_id))
+        h->pend = pend_params(cfg->env_id, cfg->real_time_scale, cfg->init_sigma, cfg->noise_layout);
     h->trig = emei_trig_table(cfg->device);
     if (!h->trig) {
         emei_destroy(h);
@@ -245,7 +272,10 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     L.seed = h->cfg.seed;
     L.env_offset = h->cfg.env_index_offset;
     L.dt = h->cfg.real_time_scale;
-    L.init_noise = h->cfg.init_noise;
+    L.integrator = h->cfg.integrator;
+    memcpy(L.noise.init, h->cfg.init_sigma, sizeof(L.noise.init));
+    memcpy(L.noise.obs, h->cfg.obs_sigma, sizeof(L.noise.obs));
+    L.noise.shared = h->cfg.noise_layout == EMEI_NOISE_SHARED;
     L.stream = (hipStream_t)stream;
     return L;
 }
@@ -347,7 +377,7 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
     if (flags & ~EMEI_FLAG_AUTO_RESET) return fail(EMEI_ERR_INVALID, "emei_rollout: unknown flags 0x%x", flags);
     if (check_action_dtype(h, action_dtype) != EMEI_OK) return EMEI_ERR_INVALID;
     int rc;
-    if (is_pend(h->cfg.env_id)) {
+    if (!steps_as_body(h->cfg)) {
         PendLaunch L = pend_base(h, stream);
         L.op = PEND_OP_ROLLOUT;
         L.actions = actions;
@@ -429,7 +459,7 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
         L.obs_in = obs;
         L.reward_out = reward_out;
         L.n = n;
-        L.p = pend_params(env_id, real_time_scale > 0 ? real_time_scale : 0.02, 0.0);
+        L.p = pend_params(env_id, real_time_scale > 0 ? real_time_scale : 0.02);
         L.trig = current_device_trig();
         L.stream = (hipStream_t)stream;
         int rc = pend_launch(L);
@@ -465,7 +495,7 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
         L.obs_in = obs;
         L.done_out = terminal_out;
         L.n = n;
-        L.p = pend_params(env_id, 0.02, 0.0);
+        L.p = pend_params(env_id, 0.02);
         L.trig = current_device_trig();
         L.stream = (hipStream_t)stream;
         int rc = pend_launch(L);
@@ -504,7 +534,7 @@ extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, c
     L.obs_out = next_obs_out;
     L.n = n;
     L.freq_rate = freq_rate;
-    L.p = pend_params(env_id, real_time_scale, 0.0);
+    L.p = pend_params(env_id, real_time_scale);
     L.trig = current_device_trig();
     L.stream = (hipStream_t)stream;
     int rc = pend_launch(L);

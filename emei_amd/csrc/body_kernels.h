@@ -3,9 +3,11 @@
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
 //   struct Model;                                   // constants, passed by value as a kernel argument
-//   substep(s, ctrl, m)                             // one MuJoCo Euler substep + emei's position override
+//   accel(q, v, ctrl, m, hd, qacc)                  // forward dynamics incl. soft constraints; `hd` = dt when
+//                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0
 //   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal)   // obs / reward / terminal of a finished step
-//   init(s, seed, env, episode, m)                  // device reset
+// The integrators (mujoco_env.py:70-79,86-97), the Gaussian init / observation noise (:98-104,
+// :197-249) and the device reset are generic and live here.
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
 //
@@ -19,6 +21,105 @@
 #include "emei_device.h"
 
 namespace emei {
+
+// per-coordinate sigmas (state order: qpos then qvel) of the Gaussian init noise and of the
+// per-substep observation noise, float32 draws; host form (any body) and kernel-argument form
+struct NoiseSpec {
+    float init[EMEI_MAX_STATE_DIM] = {0}, obs[EMEI_MAX_STATE_DIM] = {0};
+    int32_t shared = 0;  // EMEI_NOISE_SHARED: one draw for all of qpos, one for all of qvel (sigmas of joint 0)
+};
+template <int NS>
+struct NoiseArgs {
+    float init[NS], obs[NS];
+    int32_t shared, obs_on;
+    NoiseArgs() = default;
+    explicit NoiseArgs(const NoiseSpec& h) : shared(h.shared), obs_on(0) {
+        for (int i = 0; i < NS; ++i) init[i] = h.init[i], obs[i] = h.obs[i], obs_on |= h.obs[i] != 0.f;
+    }
+};
+// key tweak of the observation-noise stream (the reset stream uses the plain seed)
+constexpr uint64_t kObsNoiseKey = 0x6F62736E6F697365ull;
+
+// s (+)= sig[i] * N(0,1).  Draws: Philox counter (env, episode, blk0 + b), four normals per block in
+// coordinate order; SHARED uses the first two normals of block blk0 for every position / velocity
+// coordinate, scaled by the sigmas of joint 0 (the reference's B = 1 behaviour, mujoco_env.py:243-244).
+template <typename R, int NS, bool ASSIGN>
+__device__ __forceinline__ void gauss_state(R (&s)[NS], uint64_t key, uint64_t env, uint32_t episode, uint32_t blk0,
+                                            const float (&sig)[NS], bool shared) {
+    constexpr int NB = (NS + 3) / 4;
+    if (shared) {
+        u32x4 r = philox4x32_10(key, env, episode, blk0);
+        float z0, z1;
+        boxmuller(r.v[0], r.v[1], z0, z1);
+        const R dp = (R)__fmul_rn(sig[0], z0), dv = (R)__fmul_rn(sig[NS / 2], z1);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = (ASSIGN ? R(0) : s[i]) + (i < NS / 2 ? dp : dv);
+        return;
+    }
+    float z[4 * NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        u32x4 r = philox4x32_10(key, env, episode, blk0 + (uint32_t)b);
+        boxmuller(r.v[0], r.v[1], z[4 * b], z[4 * b + 1]);
+        boxmuller(r.v[2], r.v[3], z[4 * b + 2], z[4 * b + 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const R d = (R)__fmul_rn(sig[i], z[i]);
+        s[i] = ASSIGN ? d : s[i] + d;
+    }
+}
+// device reset: init_qpos / init_qvel + init noise (mujoco_env.py:130-140); Body::init_base adds the
+// non-zero entries of init_qpos (the Hopper's rootz ref)
+template <class Body>
+__device__ __forceinline__ void body_init(typename Body::real (&s)[Body::NS], uint64_t seed, uint64_t env, uint32_t episode,
+                                          const NoiseArgs<Body::NS>& ns) {
+    gauss_state<typename Body::real, Body::NS, true>(s, seed, env, episode, 0u, ns.init, ns.shared != 0);
+    Body::init_base(s);
+}
+
+// One substep of mujoco_env.py:91-97.  RK4 = false: MuJoCo's Euler velocity update, then either emei's
+// position override from the OLD velocity (`semi` false, :94-97,189-191) or MuJoCo's own
+// semi-implicit position update from the NEW velocity.  RK4 = true: mj_RungeKutta(4) — stage
+// states X_i = X_0 + dt*a_i*F_{i-1} (a = 1/2, 1/2, 1), X' = X_0 + dt*sum b_i F_i (b = 1/6, 1/3, 1/3, 1/6),
+// F = (v, qacc(q, v)) with the full forward dynamics (constraints included) at every stage.
+template <class Body, bool RK4>
+__device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS], const typename Body::real (&ctrl)[Body::NA],
+                                             const typename Body::Model& m, bool semi) {
+    using R = typename Body::real;
+    constexpr int NV = Body::NS / 2;
+    const R dt = (R)m.dt;
+    R q[NV], v[NV], acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q[i] = s[i], v[i] = s[NV + i];
+    if constexpr (!RK4) {
+        Body::accel(q, v, ctrl, m, dt, acc);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const R vn = fma_r(dt, acc[i], v[i]);
+            s[i] = fma_r(dt, semi ? vn : v[i], q[i]);
+            s[NV + i] = vn;
+        }
+    } else {
+        R qs[NV], vs[NV], dq[NV], dv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) qs[i] = q[i], vs[i] = v[i], dq[i] = R(0), dv[i] = R(0);
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st) {
+            Body::accel(qs, vs, ctrl, m, R(0), acc);
+            const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);
+            const R h = dt * (st == 2 ? R(1) : R(0.5));  // step to the NEXT stage state
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                dq[i] = fma_r(b, vs[i], dq[i]), dv[i] = fma_r(b, acc[i], dv[i]);
+                qs[i] = fma_r(h, vs[i], q[i]);
+                vs[i] = fma_r(h, acc[i], v[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[i] = fma_r(dt, dq[i], q[i]), s[NV + i] = fma_r(dt, dv[i], v[i]);
+    }
+}
 
 enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL };
 
@@ -42,7 +143,9 @@ struct BodyLaunch {
     int32_t n_steps = 1, freq_rate = 1, max_episode_steps = 0;
     uint32_t flags = 0;
     uint64_t seed = 0, env_offset = 0;
-    double dt = 0.002, init_noise = 0.0;
+    double dt = 0.002;
+    int32_t integrator = 0;
+    NoiseSpec noise;
     hipStream_t stream = nullptr;
 };
 int body_launch(const BodyLaunch& L);  // body_dispatch.hip
@@ -61,11 +164,13 @@ struct BodyArgs {
     int32_t n_steps, freq_rate, max_episode_steps;
     uint32_t flags;
     uint64_t seed, env_offset;
+    int32_t semi;  // EMEI_INTEG_SEMI_IMPLICIT
+    NoiseArgs<Body::NS> noise;
     typename Body::Model m;
 };
 
 // emei_step / emei_rollout (mujoco_env.py:157-167) for every env of the shard
-template <class Body>
+template <class Body, bool RK4>
 __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Body> a) {
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
@@ -94,6 +199,7 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
         for (int k = 0; k < NS; ++k) s[k] = R(0);
     }
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
+    const bool obs_noise = a.noise.obs_on != 0;
     uint32_t done = 0;
 
     // this wave's action block of step t: wave_envs*NA contiguous floats starting at (t*n + i0)*NA
@@ -129,7 +235,13 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
         R pre[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) pre[k] = s[k];
-        for (int k = 0; k < a.freq_rate; ++k) Body::substep(s, ctrl, a.m);  // mujoco_env.py:88-97
+        for (int k = 0; k < a.freq_rate; ++k) {  // mujoco_env.py:91-104
+            body_substep<Body, RK4>(s, ctrl, a.m, a.semi != 0);
+            if (obs_noise)
+                gauss_state<R, NS, false>(s, a.seed ^ kObsNoiseKey, a.env_offset + (uint64_t)i, episode,
+                                          ((uint32_t)steps * (uint32_t)a.freq_rate + (uint32_t)k) * (uint32_t)((NS + 3) / 4),
+                                          a.noise.obs, a.noise.shared != 0);
+        }
         float o[NO];
         R rew;
         bool term;
@@ -163,7 +275,7 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
             if (done != 0) {
                 ++episode;
                 steps = 0;
-                Body::init(s, a.seed, a.env_offset + (uint64_t)i, episode, a.m);
+                body_init<Body>(s, a.seed, a.env_offset + (uint64_t)i, episode, a.noise);
             }
         }
     }
@@ -180,12 +292,12 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
 template <class Body>
 __global__ void __launch_bounds__(kBlock)
     body_reset_kernel(typename Body::real* state, int32_t* steps, uint32_t* episode, int64_t n, uint64_t seed,
-                      uint64_t env_offset, typename Body::Model m) {
+                      uint64_t env_offset, NoiseArgs<Body::NS> noise) {
     using R = typename Body::real;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     R s[Body::NS];
-    Body::init(s, seed, env_offset + (uint64_t)i, 0u, m);
+    body_init<Body>(s, seed, env_offset + (uint64_t)i, 0u, noise);
 #pragma unroll
     for (int k = 0; k < Body::NS; ++k) state[(int64_t)k * n + i] = s[k];
     steps[i] = 0;
@@ -212,13 +324,13 @@ __global__ void __launch_bounds__(kBlock)
 template <class Body>
 __global__ void __launch_bounds__(kBlock)
     body_init_obs_kernel(const int64_t* env_index, const uint32_t* episode, float* obs, int64_t count, uint64_t seed,
-                         uint64_t env_offset, typename Body::Model m) {
+                         uint64_t env_offset, NoiseArgs<Body::NS> noise, typename Body::Model m) {
     using R = typename Body::real;
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
     R s[Body::NS];
     double o[Body::NO];
-    Body::init(s, seed, env_offset + (uint64_t)env_index[k], episode[k], m);
+    body_init<Body>(s, seed, env_offset + (uint64_t)env_index[k], episode[k], noise);
     Body::obs_of(s, o, m);
 #pragma unroll
     for (int j = 0; j < Body::NO; ++j) obs[k * Body::NO + j] = (float)o[j];
@@ -246,7 +358,7 @@ __global__ void __launch_bounds__(kBlock)
 template <class Body>
 static int launch_body(const BodyLaunch& L) {
     using R = typename Body::real;
-    const typename Body::Model m = Body::make_model(L.dt, L.init_noise);
+    const typename Body::Model m = Body::make_model(L.dt);
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case BODY_OP_ROLLOUT: {
@@ -255,12 +367,16 @@ static int launch_body(const BodyLaunch& L) {
             a.actions = L.actions, a.obs_out = L.obs_out, a.reward_out = L.reward_out, a.done_out = L.done_out;
             a.n = L.n, a.n_steps = L.n_steps, a.freq_rate = L.freq_rate, a.max_episode_steps = L.max_episode_steps;
             a.flags = L.flags, a.seed = L.seed, a.env_offset = L.env_offset, a.m = m;
-            hipLaunchKernelGGL(body_rollout_kernel<Body>, grid, dim3(kBlock), 0, L.stream, a);
+            a.semi = L.integrator == EMEI_INTEG_SEMI_IMPLICIT, a.noise = NoiseArgs<Body::NS>(L.noise);
+            if (L.integrator == EMEI_INTEG_RK4)
+                hipLaunchKernelGGL((body_rollout_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, a);
+            else
+                hipLaunchKernelGGL((body_rollout_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, a);
             break;
         }
         case BODY_OP_RESET:
             hipLaunchKernelGGL(body_reset_kernel<Body>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps, L.episode,
-                               L.n, L.seed, L.env_offset, m);
+                               L.n, L.seed, L.env_offset, NoiseArgs<Body::NS>(L.noise));
             break;
         case BODY_OP_GET_OBS:
             hipLaunchKernelGGL(body_get_obs_kernel<Body>, grid, dim3(kBlock), 0, L.stream, (const R*)L.state, L.obs_f64,
@@ -268,7 +384,7 @@ static int launch_body(const BodyLaunch& L) {
             break;
         case BODY_OP_INIT_OBS:
             hipLaunchKernelGGL(body_init_obs_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.env_index, L.episode_in,
-                               L.obs_out, L.n, L.seed, L.env_offset, m);
+                               L.obs_out, L.n, L.seed, L.env_offset, NoiseArgs<Body::NS>(L.noise), m);
             break;
         case BODY_OP_REWARD:
             hipLaunchKernelGGL(body_reward_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.pre_obs_in,

@@ -50,7 +50,6 @@ struct Model {
     double cK, cB, c_dmin, c_dmax, c_width;       // contact solref (refsafe'd for dt) / solimp
     double lK, lB, l_dmin, l_dmax, l_width;       // joint-limit solref / solimp
     double dt;
-    float init_sigma;
 };
 
 template <typename R>
@@ -111,9 +110,12 @@ __device__ __forceinline__ void ldl_solve(const R (&A)[NV][NV], const R (&invd)[
             if (nz(i, j)) x[j] = fma_r(-A[i][j], x[i], x[j]);
 }
 
+// Forward dynamics: qacc at (q, v) with actuator, passive and soft-constraint forces.  `hd` is the
+// time step when joint damping is treated implicitly (MuJoCo's Euler: (M + h D) qacc = f), 0 for RK4.
 // q, v in the reference's order (rootx, rootz, rooty, bthigh, bshin, bfoot, fthigh, fshin, ffoot).
 template <typename R>
-__device__ __forceinline__ void substep(R (&q)[NV], R (&v)[NV], const R (&ctrl)[6], const Model& m) {
+__device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[6], const Model& m, R hd,
+                                      R (&qacc)[NV]) {
     // ---- absolute angles / rates, permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso
     R phi[7], om[7];
     phi[6] = q[2], om[6] = v[2];
@@ -192,14 +194,13 @@ __device__ __forceinline__ void substep(R (&q)[NV], R (&v)[NV], const R (&ctrl)[
     // ---- joints: child link / parent link (permuted) for joints bthigh,bshin,bfoot,fthigh,fshin,ffoot
     constexpr int jc[6] = {P_BTHIGH, P_BSHIN, P_BFOOT, P_FTHIGH, P_FSHIN, P_FFOOT};
     constexpr int jp[6] = {P_TORSO, P_BTHIGH, P_BSHIN, P_TORSO, P_FTHIGH, P_FSHIN};
-    const R dt = (R)m.dt;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);   // ctrlrange +-1
         const R tau = (R)m.gear[k] * c - (R)m.stiff[k] * q[3 + k] - (R)m.damp[k] * v[3 + k];
         f[jc[k]] += tau;
         f[jp[k]] -= tau;
-        const R e = (R)m.arm[k] + dt * (R)m.damp[k];  // armature + implicit damping: M + h D on theta_k
+        const R e = (R)m.arm[k] + hd * (R)m.damp[k];  // armature + implicit damping: M + h D on theta_k
         A[jc[k]][jc[k]] += e;
         A[jp[k]][jp[k]] += e;
         // the (child,parent) entry lives in the lower triangle at [max][min]
@@ -313,16 +314,10 @@ __device__ __forceinline__ void substep(R (&q)[NV], R (&v)[NV], const R (&ctrl)[
     contact(14, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
     contact(15, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
 
-    // ---- back to joint coordinates and integrate: q from the OLD velocity (emei), v from MuJoCo's Euler
-    R qacc[NV];
+    // ---- back to joint coordinates
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[P_TORSO];
     qacc[3] = acc[P_BTHIGH] - acc[P_TORSO], qacc[4] = acc[P_BSHIN] - acc[P_BTHIGH], qacc[5] = acc[P_BFOOT] - acc[P_BSHIN];
     qacc[6] = acc[P_FTHIGH] - acc[P_TORSO], qacc[7] = acc[P_FSHIN] - acc[P_FTHIGH], qacc[8] = acc[P_FFOOT] - acc[P_FSHIN];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        q[i] = fma_r(dt, v[i], q[i]);
-        v[i] = fma_r(dt, qacc[i], v[i]);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,7 +334,7 @@ inline double capsule_inertia_perp(double rho, double r, double half) {
 }
 }  // namespace cheetah_host
 
-inline Model cheetah_make_model(double dt, double init_noise) {
+inline Model cheetah_make_model(double dt) {
     using namespace cheetah_host;
     Model m;
     memset(&m, 0, sizeof(m));
@@ -415,10 +410,8 @@ inline Model cheetah_make_model(double dt, double init_noise) {
     m.c_dmin = 0.0, m.c_dmax = dmax, m.c_width = 0.01;
     m.l_dmin = 0.0, m.l_dmax = dmax, m.l_width = 0.03;
     m.dt = dt;
-    m.init_sigma = (float)init_noise;
     return m;
 }
-
 
 }  // namespace cheetah
 
@@ -429,15 +422,11 @@ struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
     static constexpr int NS = 18, NO = 18, NA = 6;
-    static Model make_model(double dt, double init_noise) { return cheetah::cheetah_make_model(dt, init_noise); }
+    static Model make_model(double dt) { return cheetah::cheetah_make_model(dt); }
 
-    __device__ __forceinline__ static void substep(R (&s)[NS], const R (&ctrl)[NA], const Model& m) {
-        R q[cheetah::NV], v[cheetah::NV];
-#pragma unroll
-        for (int k = 0; k < cheetah::NV; ++k) q[k] = s[k], v[k] = s[cheetah::NV + k];
-        cheetah::substep(q, v, ctrl, m);
-#pragma unroll
-        for (int k = 0; k < cheetah::NV; ++k) s[k] = q[k], s[cheetah::NV + k] = v[k];
+    __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
+                                                 const Model& m, R hd, R (&qacc)[cheetah::NV]) {
+        cheetah::accel(q, v, ctrl, m, hd, qacc);
     }
     // obs = concat(qpos, qvel) (mujoco_env.py:153-155); reward half_cheetah.py:59-63 with step() semantics
     // (per env: w_f (x' - x)/dt_env - w_c sum a^2, dt_env = dt*freq_rate); terminal :65-67 (non-finite)
@@ -452,21 +441,10 @@ struct CheetahBody {
         for (int k = 0; k < NS; ++k) fin &= finite_r(s[k]), o[k] = (float)s[k];
         term = !fin;
     }
+    __device__ __forceinline__ static void init_base(R (&)[NS]) {}  // init_qpos = init_qvel = 0
     __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) o[k] = (double)s[k];
-    }
-    // device reset: init_qpos/qvel (zeros) + sigma N(0,1) per coordinate (mujoco_env.py:137-140)
-    __device__ __forceinline__ static void init(R (&s)[NS], uint64_t seed, uint64_t env, uint32_t episode, const Model& m) {
-        float z[20];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            u32x4 r = philox4x32_10(seed, env, episode, (uint32_t)b);
-            boxmuller(r.v[0], r.v[1], z[4 * b], z[4 * b + 1]);
-            boxmuller(r.v[2], r.v[3], z[4 * b + 2], z[4 * b + 3]);
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) s[i] = (R)__fmul_rn(m.init_sigma, z[i]);
     }
     // half_cheetah.py:59-63 for one row (the reference's batch form sums np.square(action) over the WHOLE
     // batch, a quirk documented in DESIGN.md); float32 in, float64 arithmetic

@@ -23,7 +23,6 @@ struct Model {
     double gx, gz, gear, x_lo, x_hi, margin, invw;
     double K, B, dmin, dmax, width;  // slider-limit solref (refsafe'd) / solimp
     double dt, phi_off;
-    float init_sigma;
 };
 
 namespace host {
@@ -34,7 +33,7 @@ inline double capsule_inertia_perp(double rho, double r, double half) {
 }
 }  // namespace host
 
-inline Model make_model(bool swingup, double dt, double init_noise) {
+inline Model make_model(bool swingup, double dt) {
     Model m;
     memset(&m, 0, sizeof(m));
     const double rho = 1000.0;
@@ -57,7 +56,6 @@ inline Model make_model(bool swingup, double dt, double init_noise) {
     m.dmin = 0.9, m.dmax = dmax, m.width = 0.001;
     m.dt = dt;
     m.phi_off = swingup ? M_PI : 0.0;                                         // _update_model: body_quat[2] = (0,0,1,0)
-    m.init_sigma = (float)init_noise;
     return m;
 }
 
@@ -68,12 +66,13 @@ struct DPendBody {
     using real = R;
     using Model = dpend::Model;
     static constexpr int NS = 6, NO = 6, NA = 1;
-    static Model make_model(double dt, double init_noise) { return dpend::make_model(VARIANT >= 2, dt, init_noise); }
+    static Model make_model(double dt) { return dpend::make_model(VARIANT >= 2, dt); }
 
-    // state s = (x, theta1, theta2, v, omega1, omega2)
-    __device__ __forceinline__ static void substep(R (&s)[NS], const R (&ctrl)[NA], const Model& m) {
-        const R phi1 = s[1] + (R)m.phi_off, phi2 = phi1 + s[2];
-        const R w1 = s[4], w2 = s[4] + s[5];
+    // q = (x, theta1, theta2), v = (v, omega1, omega2); no joint damping in this model, so `hd` is unused
+    __device__ __forceinline__ static void accel(const R (&q)[3], const R (&v)[3], const R (&ctrl)[NA], const Model& m, R,
+                                                 R (&qacc)[3]) {
+        const R phi1 = q[1] + (R)m.phi_off, phi2 = phi1 + q[2];
+        const R w1 = v[1], w2 = v[1] + v[2];
         R s1, c1, s2, c2;
         sincos_r(phi1, s1, c1);
         sincos_r(phi2, s2, c2);
@@ -108,8 +107,8 @@ struct DPendBody {
         solve(fx, f1, f2, ax, a1_, a2_);
         // soft slider limit with margin 0.01 (mjCNSTR_LIMIT_JOINT: active when dist < margin)
         R dist = R(0), J = R(0);
-        if (s[0] - (R)m.x_lo < (R)m.margin) dist = s[0] - (R)m.x_lo, J = R(1);
-        else if ((R)m.x_hi - s[0] < (R)m.margin) dist = (R)m.x_hi - s[0], J = R(-1);
+        if (q[0] - (R)m.x_lo < (R)m.margin) dist = q[0] - (R)m.x_lo, J = R(1);
+        else if ((R)m.x_hi - q[0] < (R)m.margin) dist = (R)m.x_hi - q[0], J = R(-1);
         if (J != R(0)) {
             R wx, w1_, w2_;
             solve(R(1), R(0), R(0), wx, w1_, w2_);
@@ -117,7 +116,7 @@ struct DPendBody {
             const R xx = fabs(pos) / (R)m.width;
             const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);
-            const R aref = -(R)m.B * (J * s[3]) - (R)m.K * imp * pos;
+            const R aref = -(R)m.B * (J * v[0]) - (R)m.K * imp * pos;
             const R Rr = (R(1) - imp) / imp * (R)m.invw;
             const R force = (aref - J * ax) / (wx + Rr);
             if (force > R(0)) {
@@ -126,13 +125,7 @@ struct DPendBody {
                 a2_ = fma_r(w2_, J * force, a2_);
             }
         }
-        const R dt = (R)m.dt;
-        s[0] = fma_r(dt, s[3], s[0]);  // get_euler_pos (mujoco_env.py:189-191): old velocities
-        s[1] = fma_r(dt, s[4], s[1]);
-        s[2] = fma_r(dt, s[5], s[2]);
-        s[3] = fma_r(dt, ax, s[3]);
-        s[4] = fma_r(dt, a1_, s[4]);
-        s[5] = fma_r(dt, a2_ - a1_, s[5]);  // theta2'' = Omega2' - Omega1'
+        qacc[0] = ax, qacc[1] = a1_, qacc[2] = a2_ - a1_;  // theta2'' = Omega2' - Omega1'
     }
 
     // inverted_double_pendulum.py:57-60: state[1:3] = (state[1:3] + pi) % 2 * pi - pi   (sic)
@@ -163,21 +156,10 @@ struct DPendBody {
 #pragma unroll
         for (int k = 0; k < NO; ++k) o[k] = (float)ob[k];
     }
+    __device__ __forceinline__ static void init_base(R (&)[NS]) {}  // init_qpos = init_qvel = 0
     __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
         o[0] = (double)s[0], o[1] = (double)quirk_wrap(s[1]), o[2] = (double)quirk_wrap(s[2]);
         o[3] = (double)s[3], o[4] = (double)s[4], o[5] = (double)s[5];
-    }
-    // device reset: zeros + sigma N(0,1) per coordinate (mujoco_env.py:137-140)
-    __device__ __forceinline__ static void init(R (&s)[NS], uint64_t seed, uint64_t env, uint32_t episode, const Model& m) {
-        float z[8];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            u32x4 r = philox4x32_10(seed, env, episode, (uint32_t)b);
-            boxmuller(r.v[0], r.v[1], z[4 * b], z[4 * b + 1]);
-            boxmuller(r.v[2], r.v[3], z[4 * b + 2], z[4 * b + 3]);
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) s[i] = (R)__fmul_rn(m.init_sigma, z[i]);
     }
     __device__ __forceinline__ static double batch_reward(const float* obs, const float*, const float*, const Model& m, int) {
         double o[NO], rew;

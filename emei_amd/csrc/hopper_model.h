@@ -1,0 +1,325 @@
+// hopper_model.h — device arithmetic of the Hopper (emei/envs/mujoco/hopper.py on mujoco_env.py;
+// model emei/envs/mujoco/assets/hopper.xml): planar 4-link chain torso-thigh-leg-foot, 6 DoF
+// (rootx, rootz, rooty, thigh, leg, foot), 3 motors, capsule/floor contacts.
+//
+// Parity with libmujoco is UNPINNED (no MuJoCo in the image).  The CPU oracle
+// (oracle/planar_oracle.c) restates the model with MuJoCo's own algorithms on a generic tree table
+// (recursive Newton-Euler, dense factorisation); this file is an independent formulation for the
+// GPU, the single-chain case of cheetah_model.h:
+//   * ABSOLUTE link angles phi_L as velocity coordinates u = (Omega_foot, Omega_leg, Omega_thigh,
+//     Omega_torso, xdot, zdot) — leaves first, so the LDL^T runs down the chain.  Inertia:
+//     M[phi_i, phi_i] = const, M[phi_i, phi_j] = D_i . S_j (i ancestor of j), M[x|z, phi_j] =
+//     perp(S_j), with S_j = R(phi_j) s_j the rotated mass-moment vector of link j (+ everything it
+//     carries) and D_i = R(phi_i) d_i link i's vector to its child joint; velocity-product forces
+//     are Omega_j^2 times the same rotated vectors: 4 sincos per forward-dynamics evaluation.
+//   * the three leg hinges turn about -y (hopper.xml:21,25,29): theta_k = -(phi_child - phi_parent),
+//     so a joint torque tau_k enters as -tau_k on phi_child and +tau_k on phi_parent.
+//   * constraints (3 joint limits, 8 capsule-end/floor contact points with margin and friction)
+//     follow the oracle: one Gauss-Seidel sweep in the same fixed order.
+// The reference steps this env with RK4 by default (hopper.py:22): body_kernels.h:body_substep.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "cheetah_model.h"  // V2, rot, dot, dotperp, impedance
+#include "emei_device.h"
+
+namespace emei {
+namespace hopper {
+
+constexpr int NV = 6, NL = 4;
+enum { L_FOOT = 0, L_LEG = 1, L_THIGH = 2, L_TORSO = 3, P_X = 4, P_Z = 5 };
+
+struct Model {
+    double sx[NL], sz[NL], diag[NL];  // mass-moment vector (link frame) and constant diagonal inertia per link
+    double d[NL][2];                  // link L's vector to the joint of link L-1 (link frame); d[0] unused
+    double mtot, gravity, z0;         // z0: world z of the torso origin at qpos[1] = 0 (body z 1.25 - ref 1.25)
+    double damp[3], arm[3], lo[3], hi[3], gear[3];  // joints thigh, leg, foot
+    double geom_end[8][2];            // capsule end-sphere centres, link frame; geom order torso, thigh, leg, foot
+    double radius[4], friction[4], margin;
+    double cK, cB, c_dmin, c_dmax, c_width;  // contact solref (refsafe'd for dt) / solimp
+    double lK, lB, l_dmin, l_dmax, l_width;  // joint-limit solref / solimp
+    double dt;
+};
+
+using cheetah::dot;
+using cheetah::dotperp;
+using cheetah::impedance;
+using cheetah::rot;
+using cheetah::V2;
+
+// dense LDL^T of the symmetric 6x6 (lower triangle of A); L in the strict lower triangle, 1/D in invd
+template <typename R>
+__device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        invd[j] = rcp_r(A[j][j]);
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) {
+            const R l = A[i][j] * invd[j];
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) A[i][k] = fma_r(-l, A[k][j], A[i][k]);
+        }
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) A[i][j] *= invd[j];
+    }
+}
+template <typename R>
+__device__ __forceinline__ void ldl_solve(const R (&A)[NV][NV], const R (&invd)[NV], R (&x)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) x[i] = fma_r(-A[i][j], x[j], x[i]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) x[j] *= invd[j];
+#pragma unroll
+    for (int j = NV - 1; j >= 0; --j)
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) x[j] = fma_r(-A[i][j], x[i], x[j]);
+}
+
+// Forward dynamics: qacc at (q, v); hd = dt for MuJoCo's Euler (implicit joint damping), 0 for RK4.
+template <typename R>
+__device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
+                                      R (&qacc)[NV]) {
+    // absolute angles / rates down the chain (hinges about -y)
+    R phi[NL], om[NL];
+    phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
+    phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
+    phi[L_LEG] = phi[L_THIGH] - q[4], om[L_LEG] = om[L_THIGH] - v[4];
+    phi[L_FOOT] = phi[L_LEG] - q[5], om[L_FOOT] = om[L_LEG] - v[5];
+    R cs[NL], sn[NL], w2[NL];
+    V2<R> S[NL], D[NL];
+#pragma unroll
+    for (int b = 0; b < NL; ++b) {
+        sincos_r(phi[b], sn[b], cs[b]);
+        S[b] = rot(cs[b], sn[b], (R)m.sx[b], (R)m.sz[b]);
+        D[b] = rot(cs[b], sn[b], (R)m.d[b][0], (R)m.d[b][1]);
+        w2[b] = om[b] * om[b];
+    }
+    // ---- inertia (lower triangle) and right-hand side in absolute coordinates
+    R A[NV][NV], f[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) A[i][j] = R(0);
+    const R g = (R)m.gravity;
+    R fx = R(0), fz = R(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        A[i][i] = (R)m.diag[i];
+        A[P_X][i] = S[i].z, A[P_Z][i] = -S[i].x;  // perp(S_i)
+        R fi = g * S[i].x;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (j < i) {  // j is carried by i
+                A[i][j] = dot(D[i], S[j]);
+                fi = fma_r(w2[j], dotperp(S[j], D[i]), fi);
+            } else if (j > i) {
+                fi = fma_r(w2[j], dotperp(D[j], S[i]), fi);
+            }
+        }
+        f[i] = fi;
+        fx = fma_r(w2[i], S[i].x, fx), fz = fma_r(w2[i], S[i].z, fz);
+    }
+    A[P_X][P_X] = (R)m.mtot, A[P_Z][P_Z] = (R)m.mtot;
+    f[P_X] = fx, f[P_Z] = fz - (R)m.mtot * g;
+    // ---- joints thigh, leg, foot: child link / parent link; theta_k = -(phi_c - phi_p)
+    constexpr int jc[3] = {L_THIGH, L_LEG, L_FOOT}, jp[3] = {L_TORSO, L_THIGH, L_LEG};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);  // ctrlrange +-1 (xml:37-39)
+        const R tau = (R)m.gear[k] * c - (R)m.damp[k] * v[3 + k];
+        f[jc[k]] -= tau;
+        f[jp[k]] += tau;
+        const R e = (R)m.arm[k] + hd * (R)m.damp[k];  // armature + implicit damping on theta_k
+        A[jc[k]][jc[k]] += e;
+        A[jp[k]][jp[k]] += e;
+        A[jp[k]][jc[k]] -= e;  // parent index > child index: lower triangle
+    }
+    R invd[NV], acc[NV];
+    ldl_factor(A, invd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = f[i];
+    ldl_solve(A, invd, acc);
+
+    // ---- soft constraints, one Gauss-Seidel sweep (oracle/planar_oracle.c order)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // joint limits on theta_k
+        const R th = q[3 + k];
+        R dist = R(0), J = R(0);
+        if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
+        else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
+        if (J != R(0)) {
+            R w[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[i] = R(0);
+            w[jc[k]] = -J, w[jp[k]] = J;  // d theta_k / d phi
+            ldl_solve(A, invd, w);
+            const R Aii = J * (w[jp[k]] - w[jc[k]]);
+            const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
+            const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+            const R Rr = (R(1) - imp) / imp * Aii;
+            const R force = (aref - J * (acc[jp[k]] - acc[jc[k]])) / (Aii + Rr);
+            if (force > R(0)) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[i] = fma_r(w[i], force, acc[i]);
+            }
+        }
+    }
+    // link origins (world): torso, then down the chain
+    V2<R> org[NL];
+    org[L_TORSO] = V2<R>{q[0], (R)m.z0 + q[1]};
+    org[L_THIGH] = V2<R>{org[L_TORSO].x + D[L_TORSO].x, org[L_TORSO].z + D[L_TORSO].z};
+    org[L_LEG] = V2<R>{org[L_THIGH].x + D[L_THIGH].x, org[L_THIGH].z + D[L_THIGH].z};
+    org[L_FOOT] = V2<R>{org[L_LEG].x + D[L_LEG].x, org[L_LEG].z + D[L_LEG].z};
+    R u[NV];
+#pragma unroll
+    for (int b = 0; b < NL; ++b) u[b] = om[b];
+    u[P_X] = v[0], u[P_Z] = v[1];
+    constexpr int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {  // capsule end spheres against the floor, geom order torso, thigh, leg, foot
+        const int gi = pt / 2, lnk = geom_link[gi];
+        const V2<R> e = rot(cs[lnk], sn[lnk], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
+        const R dist = org[lnk].z + e.z - (R)m.radius[gi];
+        if (dist < (R)m.margin) {
+            // contact point midway between the surfaces: p = (s.x, dist/2); r = p - link origin
+            const V2<R> r = {e.x, R(0.5) * dist - org[lnk].z};
+            R Jx[NV], Jz[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+            Jx[P_X] = R(1), Jz[P_Z] = R(1);
+            Jx[lnk] = r.z, Jz[lnk] = -r.x;
+#pragma unroll
+            for (int a = 1; a < NL; ++a)  // every ancestor contributes perp(its link vector)
+                if (a > lnk) Jx[a] = D[a].z, Jz[a] = -D[a].x;
+            R wx[NV], wz[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) wx[i] = Jx[i], wz[i] = Jz[i];
+            ldl_solve(A, invd, wx);
+            ldl_solve(A, invd, wz);
+            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0), vn = R(0), vt = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                Ann = fma_r(Jz[i], wz[i], Ann), Att = fma_r(Jx[i], wx[i], Att), Atn = fma_r(Jx[i], wz[i], Atn);
+                an = fma_r(Jz[i], acc[i], an), at = fma_r(Jx[i], acc[i], at);
+                vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+            }
+            const R pos = dist - (R)m.margin;
+            const R imp = impedance(pos, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
+            const R k1 = (R(1) - imp) / imp;
+            const R fn = (-(R)m.cB * vn - (R)m.cK * imp * pos - an) / (Ann + k1 * Ann);
+            if (fn > R(0)) {
+                R ft = (-(R)m.cB * vt - at - Atn * fn) / (Att + k1 * Att);
+                const R lim = (R)m.friction[gi] * fn;
+                ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[i] = fma_r(wz[i], fn, fma_r(wx[i], ft, acc[i]));
+            }
+        }
+    }
+    // ---- back to joint coordinates
+    qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[L_TORSO];
+    qacc[3] = acc[L_TORSO] - acc[L_THIGH], qacc[4] = acc[L_THIGH] - acc[L_LEG], qacc[5] = acc[L_LEG] - acc[L_FOOT];
+}
+
+// host: model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000)
+inline Model make_model(double dt) {
+    using namespace cheetah::cheetah_host;
+    Model m;
+    memset(&m, 0, sizeof(m));
+    const double rho = 1000.0, deg = M_PI / 180.0;
+    // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
+    // foot (0,.1) xml:29, leg (0,.6) :25, thigh (0,1.05) :21, torso (0,1.25) :17
+    const double half[NL] = {0.195, 0.25, 0.225, 0.2}, rad[NL] = {0.06, 0.04, 0.05, 0.05};  // capsules :30,26,22,18
+    const H2 gc[NL] = {{0.065, 0}, {0, -0.25}, {0, -0.225}, {0, 0}};     // capsule centres, link frame
+    const double gang[NL] = {M_PI / 2, 0, 0, 0};                          // foot capsule lies along x
+    const H2 dvec[NL] = {{0, 0}, {0, -0.5}, {0, -0.45}, {0, -0.2}};       // to the child joint
+    double mass[NL], inertia[NL], sub[NL];
+    for (int b = 0; b < NL; ++b) {
+        mass[b] = capsule_mass(rho, rad[b], half[b]);
+        inertia[b] = capsule_inertia_perp(rho, rad[b], half[b]);
+        sub[b] = mass[b] + (b ? sub[b - 1] : 0.0);  // link b carries links 0..b-1
+    }
+    for (int b = 0; b < NL; ++b) {
+        const double carried = b ? sub[b - 1] : 0.0;
+        m.sx[b] = mass[b] * gc[b].x + carried * dvec[b].x, m.sz[b] = mass[b] * gc[b].z + carried * dvec[b].z;
+        m.diag[b] = inertia[b] + mass[b] * (gc[b].x * gc[b].x + gc[b].z * gc[b].z) +
+                    carried * (dvec[b].x * dvec[b].x + dvec[b].z * dvec[b].z);
+        m.d[b][0] = dvec[b].x, m.d[b][1] = dvec[b].z;
+    }
+    m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = 1.25 - 1.25;  // body pos z 1.25, rootz ref 1.25 (:16)
+    const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};  // :21,25,29
+    for (int k = 0; k < 3; ++k) m.damp[k] = 1.0, m.arm[k] = 1.0, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = 200.0;  // :5,37-39
+    const int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
+    for (int g = 0; g < 4; ++g) {
+        const int b = geom_link[g];
+        const H2 ax = hrot(gang[b], {0, 1});
+        m.geom_end[2 * g][0] = gc[b].x - half[b] * ax.x, m.geom_end[2 * g][1] = gc[b].z - half[b] * ax.z;
+        m.geom_end[2 * g + 1][0] = gc[b].x + half[b] * ax.x, m.geom_end[2 * g + 1][1] = gc[b].z + half[b] * ax.z;
+        m.radius[g] = rad[b];
+        m.friction[g] = g == 3 ? 2.0 : 1.0;  // max(floor 1.0, geom .9 | 2.0) (:18,22,26,30)
+    }
+    m.margin = 0.001;  // :6
+    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02;  // solref (.02 1), refsafe
+    m.c_dmin = 0.8, m.c_dmax = 0.8, m.c_width = 0.01;  // geom solimp (.8 .8 .01) :6
+    m.l_dmin = 0.9, m.l_dmax = 0.95, m.l_width = 0.001;  // MuJoCo's joint-limit defaults
+    m.cK = 1.0 / (m.c_dmax * m.c_dmax * tc * tc), m.cB = 2.0 / (m.c_dmax * tc);
+    m.lK = 1.0 / (m.l_dmax * m.l_dmax * tc * tc), m.lB = 2.0 / (m.l_dmax * tc);
+    m.dt = dt;
+    return m;
+}
+
+}  // namespace hopper
+
+// Body traits for body_kernels.h
+template <typename R>
+struct HopperBody {
+    using real = R;
+    using Model = hopper::Model;
+    static constexpr int NS = 12, NO = 12, NA = 3;
+    static Model make_model(double dt) { return hopper::make_model(dt); }
+
+    __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
+                                                 R (&qacc)[6]) {
+        hopper::accel(q, v, ctrl, m, hd, qacc);
+    }
+    // hopper.py:79-93 as executed: np.logical_and(healthy_state, healthy_z, healthy_angle) takes the
+    // third argument as `out=`, so the angle range is never applied
+    template <typename T>
+    __device__ __forceinline__ static bool is_healthy(const T* o) {
+        bool st = true;
+#pragma unroll
+        for (int k = 2; k < NO; ++k) st &= (T(-100) < o[k]) & (o[k] < T(100));
+        return st & (T(0.7) < o[1]) & (o[1] < T(INFINITY));
+    }
+    // obs = concat(qpos, qvel) (mujoco_env.py:153-155).  reward (hopper.py:95-102): healthy_reward is
+    // (is_healthy | terminate_when_unhealthy) * 1 = 1 for the default flag; + w_f (x' - x)/dt_env
+    // - 1e-3 sum a^2 (per env, step() semantics).  terminal (:104-106) = ~(is_healthy | True) = False.
+    __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+        R cost = R(0);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);
+        rew = R(1) + (s[0] - pre[0]) / ((R)m.dt * (R)freq_rate) - R(1e-3) * cost;
+        term = false;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) o[k] = (float)s[k];
+    }
+    __device__ __forceinline__ static void init_base(R (&s)[NS]) { s[1] += R(1.25); }  // init_qpos[rootz] = ref (xml:16)
+    __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) o[k] = (double)s[k];
+    }
+    __device__ __forceinline__ static double batch_reward(const float* obs, const float* pre_obs, const float* act,
+                                                          const Model& m, int freq_rate) {
+        double cost = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
+        return 1.0 + ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - 1e-3 * cost;
+    }
+    __device__ __forceinline__ static bool batch_terminal(const float*, const Model&) { return false; }
+};
+
+}  // namespace emei

@@ -20,7 +20,8 @@ namespace emei {
 struct PendParams {
     double dt;   // real_time_scale: the time step of ONE substep (base_control.py:73; mujoco_env.py:69)
     float dt32;  // float32(dt): the weak-scalar promotion of `derivs(y) * dt` (base_control.py:164)
-    float init_sigma;
+    float init_sigma[4];               // Gaussian init noise per coordinate (x, theta, v, omega) (mujoco_env.py:137-140)
+    int32_t noise_shared;              // EMEI_NOISE_SHARED: the reference's B = 1 row-slicing layout (:243-244)
     // InvertedPendulum model (see oracle/emei_oracle.c:emei_oracle_ip_model for the derivation)
     double M11, M22, mpr, mgr, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
     double sin_off, cos_off, phi_off;  // phi = theta + phi_off is the com angle from +z
@@ -263,15 +264,21 @@ struct InvPend {
         term = terminal(o, c, p);
     }
 
-    // device reset: init_qpos/qvel (zeros) + sigma * N(0,1) per coordinate (mujoco_env.py:137-140)
+    // device reset: init_qpos/qvel (zeros) + sigma * N(0,1) (mujoco_env.py:137-140); same draws as
+    // body_kernels.h:gauss_state so both rollout paths of this env reset identically
     __device__ __forceinline__ static void init(R s[4], uint64_t seed, uint64_t env, uint32_t episode,
                                                 const PendParams& p) {
         u32x4 r = philox4x32_10(seed, env, episode, 0);
         float z[4];
         boxmuller(r.v[0], r.v[1], z[0], z[1]);
         boxmuller(r.v[2], r.v[3], z[2], z[3]);
+        if (p.noise_shared) {
+            s[0] = s[1] = (R)__fmul_rn(p.init_sigma[0], z[0]);
+            s[2] = s[3] = (R)__fmul_rn(p.init_sigma[2], z[1]);
+            return;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] = (R)__fmul_rn(p.init_sigma, z[i]);
+        for (int i = 0; i < 4; ++i) s[i] = (R)__fmul_rn(p.init_sigma[i], z[i]);
     }
 };
 

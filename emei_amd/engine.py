@@ -32,13 +32,31 @@ def env_dims(env_name):
     return od.value, ad.value, sd.value
 
 
+def _sigmas(x, state_dim):
+    """float -> the same sigma everywhere; (pos, vel) -> per half; a sequence of state_dim values as given."""
+    half = state_dim // 2
+    if isinstance(x, (int, float)):
+        return [float(x)] * state_dim
+    x = [float(v) for v in x]
+    if len(x) == 2 and state_dim != 2:
+        return [x[0]] * half + [x[1]] * half
+    if len(x) != state_dim:
+        raise ValueError(f"noise sigmas {x!r}: expected a float, a (pos, vel) pair or {state_dim} values")
+    return x
+
+
 class Engine:
     """N independent env instances of one kind on one GPU (this rank's shard)."""
 
     def __init__(self, env_name, n_envs, freq_rate=1, real_time_scale=0.02, precision="ref", max_episode_steps=0,
-                 device=None, seed=0, env_index_offset=0, init_noise=0.0):
+                 device=None, seed=0, env_index_offset=0, init_noise=0.0, integrator="euler", obs_noise=0.0,
+                 noise_layout="iid"):
+        """init_noise / obs_noise: one sigma, a (qpos sigma, qvel sigma) pair, or one sigma per state coordinate
+        (qpos entries then qvel entries): the reduced forms of mujoco_env.py:218-227."""
         if env_name not in L.ENV_IDS:
             raise ValueError(f"unknown env {env_name!r}; known: {sorted(L.ENV_IDS)}")
+        if integrator not in L.INTEGRATORS:
+            raise NotImplementedError(f"integrator {integrator!r}")  # mujoco_env.py:78-79
         if not torch.cuda.is_available():
             raise L.EmeiHipError("emei_amd needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -46,9 +64,13 @@ class Engine:
         self.freq_rate, self.real_time_scale = int(freq_rate), float(real_time_scale)
         self.precision = {"ref": L.PRECISION_REF, "f32": L.PRECISION_F32}[precision]
         self.obs_dim, self.act_dim, self.state_dim = env_dims(env_name)
+        self.integrator = integrator
+        sig = C.c_float * L.MAX_STATE_DIM
         cfg = L.EmeiConfig(C.sizeof(L.EmeiConfig), L.ENV_IDS[env_name], self.n_envs, self.freq_rate, self.precision,
                            self.real_time_scale, int(max_episode_steps), self.device.index, int(seed),
-                           int(env_index_offset), float(init_noise))
+                           int(env_index_offset), 0.0, L.INTEGRATORS[integrator],
+                           {"iid": L.NOISE_IID, "shared": L.NOISE_SHARED}[noise_layout],
+                           sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(L.lib().emei_create(C.byref(cfg), C.byref(self._h)))

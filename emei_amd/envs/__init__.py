@@ -1,5 +1,6 @@
 from .cartpole import BaseCartPoleEnv, CartPoleBalancingEnv, CartPoleSwingUpEnv
 from .half_cheetah import HalfCheetahRunningEnv
+from .hopper import HopperRunningEnv
 from .inverted_double_pendulum import (
     BaseInvertedDoublePendulumEnv,
     BoundaryInvertedDoublePendulumBalancingEnv,

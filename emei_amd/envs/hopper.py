@@ -1,0 +1,48 @@
+"""Hopper running env on the HIP engine (reference: emei/envs/mujoco/hopper.py on mujoco_env.py; model
+assets/hopper.xml).  Dynamics: the planar 4-link chain in closed form (emei_amd/csrc/hopper_model.h),
+stepped with RK4 by default like the reference (:22); parity with libmujoco is unpinned.
+
+Reference behaviour kept as it EXECUTES: ``np.logical_and(healthy_state, healthy_z,
+healthy_angle)`` passes the angle test as ``out=`` so it never applies (:91); with the default
+``terminate_when_unhealthy=True`` the healthy reward is always 1 (:99) and ``terminal`` is always False
+(:104-106)."""
+import numpy as np
+
+from .. import spaces
+from .base import MujocoHipEnv
+
+
+class HopperRunningEnv(MujocoHipEnv):
+    ENGINE_NAME = "HopperRunning"
+    NQ = 6
+    INIT_QPOS = (0.0, 1.25, 0.0, 0.0, 0.0, 0.0)  # rootz ref (hopper.xml:16)
+
+    def __init__(self, freq_rate: int = 4, real_time_scale: float = 0.002, integrator: str = "rk4",
+                 init_noise_params=5e-3, obs_noise_params=0.0, forward_reward_weight: float = 1.0,
+                 ctrl_cost_weight: float = 1e-3, healthy_reward: float = 1.0, terminate_when_unhealthy: bool = True,
+                 healthy_state_range=(-100.0, 100.0), healthy_z_range=(0.7, float("inf")),
+                 healthy_angle_range=(-0.2, 0.2), **kwargs):
+        defaults = (1.0, 1e-3, 1.0, True, (-100.0, 100.0), (0.7, float("inf")))
+        if (forward_reward_weight, ctrl_cost_weight, healthy_reward, terminate_when_unhealthy, tuple(healthy_state_range),
+                tuple(healthy_z_range)) != defaults:
+            raise NotImplementedError("only the default reward / health parameters (hopper.py:25-30) are compiled in")
+        self._forward_reward_weight = forward_reward_weight
+        self._ctrl_cost_weight = ctrl_cost_weight
+        self._healthy_reward = healthy_reward
+        self._terminate_when_unhealthy = terminate_when_unhealthy
+        self._healthy_state_range = healthy_state_range
+        self._healthy_z_range = healthy_z_range
+        self._healthy_angle_range = healthy_angle_range  # accepted and, like the reference, never applied (:91)
+        super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator,
+                         init_noise_params=init_noise_params, obs_noise_params=obs_noise_params, **kwargs)
+        self.observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=(12,), dtype=np.float64)
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(3,), dtype=np.float32)  # ctrlrange, xml:37-39
+
+    def is_healthy(self, next_obs):
+        """hopper.py:79-93 as executed (host-side helper; the fused kernels carry their own copy)."""
+        next_obs = np.asarray(next_obs)
+        z = next_obs[:, 1]
+        state = next_obs[:, 2:]
+        lo, hi = self._healthy_state_range
+        zlo, zhi = self._healthy_z_range
+        return np.all((lo < state) & (state < hi), axis=1) & (zlo < z) & (z < zhi)

@@ -7,58 +7,28 @@ observation has 6 entries (:29)."""
 import numpy as np
 
 from .. import spaces
-from .base import HipEnv
+from .base import MujocoHipEnv
 
 
-class BaseInvertedDoublePendulumEnv(HipEnv):
+class BaseInvertedDoublePendulumEnv(MujocoHipEnv):
     ENGINE_NAME = "BoundaryInvertedDoublePendulumBalancing"
+    NQ = 3
 
     def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator="euler",
                  init_noise_params=5e-3, obs_noise_params=0.0, **kwargs):
-        if integrator != "euler":
-            raise NotImplementedError(f"integrator {integrator!r}: only 'euler' is implemented on the HIP engine")
-        if obs_noise_params != 0:
-            raise NotImplementedError("obs_noise_params != 0 (mujoco_env.py:98-104) is not implemented")
-        if not isinstance(init_noise_params, (int, float)):
-            raise NotImplementedError("tuple/dict init_noise_params (mujoco_env.py:218-227) are not implemented")
-        self.init_noise_params = init_noise_params
-        self.obs_noise_params = obs_noise_params
         super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator,
-                         init_noise=float(init_noise_params), **kwargs)
+                         init_noise_params=init_noise_params, obs_noise_params=obs_noise_params, **kwargs)
         self.observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=(4,), dtype=np.float64)  # sic, :29
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32)  # ctrlrange, xml:45
-        self.init_qpos = np.zeros(3)
-        self.init_qvel = np.zeros(3)
         # the reference stores this under `_causal_graph`, so get_transition_graph() finds None (:42)
         self._causal_graph = np.array([[0, 0, 0, 0, 0, 0], [0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1], [1, 0, 0, 0, 0, 0],
                                        [0, 1, 0, 1, 1, 1], [0, 0, 1, 1, 1, 1], [0, 0, 0, 1, 1, 1]])
         self.jnt_range = np.array([[-3.0, 3.0], [0.0, 0.0], [0.0, 0.0]])
 
-    def _check_single_action(self, action):
-        a = np.asarray(action, dtype=np.float32)
-        if a.shape != (1,):
-            raise ValueError(f"Action dimension mismatch. Expected (1,), found {a.shape}")
-        return a
-
-    def _host_init_state(self, batch_size):
-        sigma = float(self.init_noise_params)
-        if batch_size == 1:  # B = 1 row-slicing quirk of additive_gaussian_noise (mujoco_env.py:243-244)
-            e = [np.random.randn(1, 1) for _ in range(6)]
-            return np.concatenate([self.init_qpos[None, :] + e[0] * sigma, self.init_qvel[None, :] + e[1] * sigma], axis=1)
-        return self.np_random.standard_normal((batch_size, 6)) * sigma
-
     def _state_to_obs_np(self, state):
         obs = state.copy()
         obs[:, 1:3] = (obs[:, 1:3] + np.pi) % 2 * np.pi - np.pi  # :59, operator precedence as in the reference
         return obs
-
-    def get_batch_init_state(self, batch_size):
-        s = self._host_init_state(batch_size)
-        return s[:, :3], s[:, 3:]
-
-    def transform_state_to_obs(self, batch_state):
-        pos, vel = batch_state
-        return np.concatenate([pos, vel], axis=1)
 
 
 class ReboundInvertedDoublePendulumBalancingEnv(BaseInvertedDoublePendulumEnv):

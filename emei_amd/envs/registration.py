@@ -5,6 +5,7 @@ reference registers (``max_episode_steps``), realised on the device as the `trun
 """
 from .cartpole import CartPoleBalancingEnv, CartPoleSwingUpEnv
 from .half_cheetah import HalfCheetahRunningEnv
+from .hopper import HopperRunningEnv
 from .inverted_double_pendulum import (
     BoundaryInvertedDoublePendulumBalancingEnv,
     BoundaryInvertedDoublePendulumSwingUpEnv,
@@ -31,6 +32,7 @@ REGISTRY = {
     "BoundaryInvertedDoublePendulumSwingUp-v0": (BoundaryInvertedDoublePendulumSwingUpEnv, 1000),
     "BoundaryInvertedDoublePendulumBalancing-v0": (BoundaryInvertedDoublePendulumBalancingEnv, 1000),
     "HalfCheetahRunning-v0": (HalfCheetahRunningEnv, 1000),
+    "HopperRunning-v0": (HopperRunningEnv, 1000),  # register_env.py:87-91
 }
 
 

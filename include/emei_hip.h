@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EMEI_ABI_VERSION 1
+#define EMEI_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -41,7 +41,8 @@ enum emei_env_id {
     EMEI_IDP_BOUNDARY_BALANCING = 8, /* emei/envs/mujoco/inverted_double_pendulum.py:93-123  */
     EMEI_IDP_REBOUND_SWINGUP = 9,    /* emei/envs/mujoco/inverted_double_pendulum.py:126-153 */
     EMEI_IDP_BOUNDARY_SWINGUP = 10,  /* emei/envs/mujoco/inverted_double_pendulum.py:156-196 */
-    EMEI_NUM_ENVS_IDS = 11
+    EMEI_HOPPER_RUNNING = 11,        /* emei/envs/mujoco/hopper.py:17-106 */
+    EMEI_NUM_ENVS_IDS = 12
 };
 
 /* Arithmetic the kernels compute in.
@@ -50,6 +51,19 @@ enum emei_env_id {
  *        cartpole.py:60; MuJoCo bodies: float64 throughout).  State arrays in HBM are float64.
  * F32  : float32 state and arithmetic (fast mode; not bit-faithful on long chaotic trajectories). */
 enum emei_precision { EMEI_PRECISION_REF = 0, EMEI_PRECISION_F32 = 1 };
+
+/* Time integrator of the MuJoCo-backed bodies (mujoco_env.py:70-79).  Classic control ignores the
+ * kwarg exactly like the reference (base_control.py:73 never forwards `method`).
+ * EULER          : MuJoCo Euler velocity update + emei's position override q += dt*v_old (:94-97,169-195)
+ * SEMI_IMPLICIT  : MuJoCo Euler as it is: v' = v + dt*qacc, q += dt*v'
+ * RK4            : MuJoCo's 4-stage Runge-Kutta (mjINT_RK4): full forward dynamics at every stage */
+enum emei_integrator { EMEI_INTEG_EULER = 0, EMEI_INTEG_SEMI_IMPLICIT = 1, EMEI_INTEG_RK4 = 2 };
+
+/* How Gaussian init / observation noise is laid out over the coordinates of one env.
+ * IID      : an independent draw per coordinate (the evident intent of additive_gaussian_noise)
+ * SHARED   : what the reference actually does for its only working batch size, B = 1: the row
+ *            slicing of mujoco_env.py:243-244 adds ONE draw to every qpos entry and ONE to every qvel */
+enum emei_noise_layout { EMEI_NOISE_IID = 0, EMEI_NOISE_SHARED = 1 };
 
 /* dtype of the `actions` argument of emei_step / emei_rollout. */
 enum emei_action_dtype { EMEI_ACT_U8 = 0, EMEI_ACT_I32 = 1, EMEI_ACT_I64 = 2, EMEI_ACT_F32 = 3 };
@@ -68,6 +82,8 @@ enum emei_action_dtype { EMEI_ACT_U8 = 0, EMEI_ACT_I32 = 1, EMEI_ACT_I64 = 2, EM
 #define EMEI_ERR_UNSUPPORTED -3 /* the reference raises NotImplementedError here */
 #define EMEI_ERR_STATE -4       /* call order: e.g. step before reset (base_control.py:67) */
 
+#define EMEI_MAX_STATE_DIM 32
+
 typedef struct emei_env emei_env; /* opaque */
 
 typedef struct emei_config {
@@ -81,8 +97,21 @@ typedef struct emei_config {
     int32_t device;             /* HIP device ordinal */
     uint64_t seed;              /* key of the device-side reset generator */
     uint64_t env_index_offset;  /* global index of env 0 of this shard (results independent of sharding) */
-    double init_noise;          /* sigma of the Gaussian init noise of the MuJoCo bodies (mujoco_env.py:31) */
+    double init_noise;          /* sigma of the Gaussian init noise on qpos of the MuJoCo bodies (mujoco_env.py:31) */
+    /* -- fields below exist from ABI version 2 (struct_size 328); a version-1 caller (struct_size 64)
+     *    gets integrator = EULER, IID layout, init_sigma[*] = init_noise, no observation noise.  A
+     *    version-2 caller states every sigma in the arrays; `init_noise` above is then ignored. ------ */
+    int32_t integrator;         /* enum emei_integrator (mujoco_env.py:70-79) */
+    int32_t noise_layout;       /* enum emei_noise_layout */
+    /* Per-coordinate sigmas in state order (qpos entries, then qvel entries): the float, (pos, vel)
+     * tuple and {joint: (pos, vel)} dict forms of init_noise_params / obs_noise_params
+     * (mujoco_env.py:218-227) all reduce to this.  obs_sigma is the noise added to the state after
+     * EVERY substep (mujoco_env.py:98-104); all zero = off.  With the SHARED layout only the entries
+     * of joint 0 (index 0 and state_dim/2) are used, as in the reference. */
+    float init_sigma[EMEI_MAX_STATE_DIM];
+    float obs_sigma[EMEI_MAX_STATE_DIM];
 } emei_config;
+#define EMEI_CONFIG_SIZE_V1 64u
 
 /* -- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces Env.__init__(freq_rate, real_time_scale, integrator, ...) (base_control.py:14-30;

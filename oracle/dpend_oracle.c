@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "integrators.h"
+
 #define EXPORT __attribute__((visibility("default")))
 
 typedef struct {
@@ -81,8 +83,13 @@ EXPORT void dpend_oracle_model(dp_model_t* m, double dt) {
     m->invw = w[0]; /* dof_invweight0 of the slider at qpos0 (compiled model: poles upright) */
 }
 
-static void dp_substep(const dp_model_t* m, double off, double dt, double* q, double* v, double u) {
-    double M[3][3], bias[3], rhs[3], acc[3];
+typedef struct { const dp_model_t* m; double off; } dp_ctx_t;
+/* forward dynamics (no joint damping: hd unused); integrators in integrators.h */
+static void dp_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl_in, double* acc) {
+    const dp_model_t* m = ((const dp_ctx_t*)ctx)->m;
+    const double off = ((const dp_ctx_t*)ctx)->off, u = ctrl_in[0];
+    (void)dt, (void)hd;
+    double M[3][3], bias[3], rhs[3];
     dp_dynamics(m, off, q, v, M, bias);
     double ctrl = u < -1 ? -1 : (u > 1 ? 1 : u);
     rhs[0] = m->gear * ctrl - bias[0], rhs[1] = -bias[1], rhs[2] = -bias[2];
@@ -102,10 +109,6 @@ static void dp_substep(const dp_model_t* m, double off, double dt, double* q, do
         double R = (1 - imp) / imp * m->invw;
         double force = (aref - J * acc[0]) / (w[0] + R);
         if (force > 0) for (int i = 0; i < 3; ++i) acc[i] += w[i] * J * force;
-    }
-    for (int i = 0; i < 3; ++i) {
-        q[i] += dt * v[i];   /* position from the OLD velocity (mujoco_env.py:189-191) */
-        v[i] += dt * acc[i];
     }
 }
 
@@ -130,19 +133,24 @@ static void dp_reward_terminal(int variant, const double* o, double* rew, uint8_
 }
 
 /* mujoco_env.py:157-167 for a batch: state [n,6] = (x, th1, th2, v, w1, w2) in/out; obs [n,6] with the wrap */
-EXPORT void dpend_oracle_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
-                              double* obs, double* reward, uint8_t* terminal) {
+EXPORT void dpend_oracle_step_ex(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
+                                 double* obs, double* reward, uint8_t* terminal, const oracle_opts_t* opts) {
     dp_model_t m;
     dpend_oracle_model(&m, dt);
-    const double off = variant >= 2 ? M_PI : 0.0; /* _update_model: pole body turned by pi (:139-141,170-172) */
+    dp_ctx_t ctx = {&m, variant >= 2 ? M_PI : 0.0}; /* _update_model: pole body turned by pi (:139-141,170-172) */
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double* s = state + 6 * i;
-        for (int k = 0; k < freq_rate; ++k) dp_substep(&m, off, dt, s, s + 3, action[i]);
+        oracle_env_step(dp_accel, &ctx, 3, freq_rate, dt, opts, i, s, s + 3, action + i);
         double* o = obs + 6 * i;
         o[0] = s[0], o[1] = quirk_wrap(s[1]), o[2] = quirk_wrap(s[2]), o[3] = s[3], o[4] = s[4], o[5] = s[5];
         dp_reward_terminal(variant, o, reward + i, terminal + i);
     }
+}
+
+EXPORT void dpend_oracle_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
+                              double* obs, double* reward, uint8_t* terminal) {
+    dpend_oracle_step_ex(variant, n, freq_rate, dt, state, action, obs, reward, terminal, NULL);
 }
 
 EXPORT void dpend_oracle_reward_terminal(int variant, int64_t n, const double* obs, double* reward, uint8_t* terminal) {

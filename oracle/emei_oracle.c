@@ -190,16 +190,8 @@ EXPORT void emei_oracle_cartpole_init_f32(int variant, uint64_t seed, uint64_t e
     if (variant == 0) s[2] += (float)M_PI;
 }
 
-/* Box-Muller pair from two Philox words (device-side Gaussian init noise, mujoco_env.py:137-140
- * distribution; the reference draws from the global numpy MT19937 stream on the host). */
-static inline void boxmuller(uint32_t a, uint32_t b, float* z0, float* z1) {
-    float u1 = ((float)(a >> 8) + 1.0f) * 0x1.0p-24f; /* (0,1] */
-    float u2 = u01(b);
-    float rad = sqrtf(-2.0f * logf(u1));
-    float ang = 6.283185307179586f * u2;
-    *z0 = rad * cosf(ang);
-    *z1 = rad * sinf(ang);
-}
+#include "integrators.h"
+#define boxmuller oracle_boxmuller /* float32 Box-Muller of the device reset (integrators.h) */
 
 /* ------------------------------------------------------------------------------------------
  * InvertedPendulum (MuJoCo-backed; dynamics parity UNPINNED — see header).
@@ -255,9 +247,14 @@ EXPORT int emei_oracle_ip_model_size(void) { return (int)sizeof(ip_model_t); }
 static inline int ip_is_swingup(int variant) { return variant >= 2; }
 static inline int ip_is_rebound(int variant) { return (variant & 1) == 0; }
 
-/* One MuJoCo Euler substep + emei's position override (mujoco_env.py:91-97):
- *   qacc at (q_old, v_old); v_new = v_old + dt*qacc; q_new = q_old + dt*v_old (:181,189-191). */
-static void ip_substep(const ip_model_t* m, int variant, double dt, double q[2], double v[2], double u) {
+/* Forward dynamics of the 2-DoF model: qacc at (q, v) with the actuator and the soft slider limit.
+ * The integrators around it (mujoco_env.py:70-79,91-97) are in integrators.h. */
+typedef struct { const ip_model_t* m; int variant; } ip_ctx_t;
+static void ip_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl_in, double* qacc) {
+    const ip_model_t* m = ((const ip_ctx_t*)ctx)->m;
+    const int variant = ((const ip_ctx_t*)ctx)->variant;
+    const double u = ctrl_in[0];
+    (void)hd; /* no joint damping in this model */
     /* SwingUp's _update_model (inverted_pendulum.py:135-137,170-172) turns the pole body by pi about y */
     double phi = q[1] + m->phi0 + (ip_is_swingup(variant) ? M_PI : 0.0);
     double s = sin(phi), c = cos(phi);
@@ -292,10 +289,7 @@ static void ip_substep(const ip_model_t* m, int variant, double dt, double q[2],
             a1 += (-M12 / det) * J * force;
         }
     }
-    double qn0 = q[0] + dt * v[0], qn1 = q[1] + dt * v[1];
-    v[0] += dt * a0;
-    v[1] += dt * a1;
-    q[0] = qn0, q[1] = qn1;
+    qacc[0] = a0, qacc[1] = a1;
 }
 
 /* inverted_pendulum.py:45-49: theta_obs = (theta + pi) % (2 pi) - pi  (Python/NumPy floored mod) */
@@ -341,20 +335,33 @@ EXPORT void emei_oracle_ip_wrap(int64_t n, const double* th, double* out) {
 /* mujoco_env.py:157-167 for a batch.  state [n,4] = (x, theta, v, omega) with theta UNWRAPPED (the
  * internal qpos, inverted_pendulum.py:45-49 wraps only the observation); obs [n,4] is written
  * with the wrapped angle; action [n] float64. */
-EXPORT void emei_oracle_ip_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
-                                double* obs, double* reward, uint8_t* terminal) {
+EXPORT void emei_oracle_ip_step_ex(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
+                                   double* obs, double* reward, uint8_t* terminal, const oracle_opts_t* opts) {
     ip_model_t m;
     emei_oracle_ip_model(&m);
+    ip_ctx_t ctx = {&m, variant};
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double q[2] = {state[4 * i], state[4 * i + 1]}, v[2] = {state[4 * i + 2], state[4 * i + 3]};
-        for (int s = 0; s < freq_rate; ++s) ip_substep(&m, variant, dt, q, v, action[i]);
+        oracle_env_step(ip_accel, &ctx, 2, freq_rate, dt, opts, i, q, v, action + i);
         state[4 * i] = q[0], state[4 * i + 1] = q[1], state[4 * i + 2] = v[0], state[4 * i + 3] = v[1];
         double o[4] = {q[0], ip_wrap(q[1]), v[0], v[1]};
         memcpy(obs + 4 * i, o, sizeof(o));
         reward[i] = ip_reward(variant, o);
         terminal[i] = ip_terminal(&m, variant, o);
     }
+}
+
+EXPORT void emei_oracle_ip_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
+                                double* obs, double* reward, uint8_t* terminal) {
+    emei_oracle_ip_step_ex(variant, n, freq_rate, dt, state, action, obs, reward, terminal, NULL);
+}
+
+/* Device-side init of any MuJoCo-backed body: init_qpos/qvel = 0 + Gaussian noise, layout per `shared`
+ * (body_kernels.h:body_init).  s = (q[nv], v[nv]) float64 holding float32-rounded draws. */
+EXPORT void emei_oracle_body_init(uint64_t seed, uint64_t env, uint32_t episode, int nv, float sigma_pos, float sigma_vel,
+                                  int shared, double* s) {
+    oracle_gauss_state(seed, env, episode, 0u, nv, sigma_pos, sigma_vel, shared, 1, s, s + nv);
 }
 
 /* Device-side init for InvertedPendulum: zeros + sigma * N(0,1) i.i.d. per coordinate (the

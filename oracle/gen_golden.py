@@ -140,9 +140,10 @@ def import_reference(ref_root):
     from emei.envs.mujoco import half_cheetah as hc
     from emei.envs.mujoco import mujoco_env as me
     from emei.envs.mujoco import inverted_double_pendulum as idp
+    from emei.envs.mujoco import hopper as hp
     from emei import core
 
-    return NS(cp=cp, ip=ip, hc=hc, me=me, core=core, idp=idp)
+    return NS(cp=cp, ip=ip, hc=hc, me=me, core=core, idp=idp, hp=hp)
 
 
 # --------------------------------------------------------------------------- inputs
@@ -428,6 +429,52 @@ def gen_dpend_firstparty(ref, out):
     return data
 
 
+def gen_hopper_firstparty(ref, out):
+    """Hopper: is_healthy / reward / terminal (hopper.py:79-106) called unbound on a stand-in self with
+    the constructor defaults (:25-31), and the tuple / dict forms of additive_gaussian_noise
+    (mujoco_env.py:218-227) for B = 1 on the 6-joint chain (test/test_envs/test_mujoco/test_hopper.py:38-53)."""
+    data = {}
+    rng = np.random.default_rng(9091)
+    hp = ref.hp
+    cls = hp.HopperRunningEnv
+    f = NS(_forward_reward_weight=1.0, _ctrl_cost_weight=1e-3, _healthy_reward=1.0, _terminate_when_unhealthy=True,
+           _healthy_state_range=(-100.0, 100.0), _healthy_z_range=(0.7, float("inf")), _healthy_angle_range=(-0.2, 0.2),
+           dt=0.002 * 4)
+    f.is_healthy = lambda o: cls.is_healthy(f, o)
+    B = 256
+    o = rng.normal(0, 1, (B, 12))
+    o[:, 1] = rng.uniform(0.3, 1.6, B)          # z around the 0.7 threshold
+    o[:, 2] = rng.uniform(-0.5, 0.5, B)         # angle around +-0.2 (never applied, see hopper.py:91)
+    o[: B // 8, 6:] = rng.normal(0, 80, (B // 8, 6))  # some velocities beyond +-100
+    o[0, 1], o[1, 1] = 0.7, np.nextafter(0.7, 1.0)
+    o[2, 5], o[3, 5] = 100.0, np.nextafter(100.0, 0.0)
+    o[4, 7] = np.nan
+    o[5, 1] = np.inf
+    po = o + rng.normal(0, 0.01, (B, 12))
+    a = rng.uniform(-1, 1, (B, 3))
+    with np.errstate(all="ignore"):
+        data["hopper_obs"], data["hopper_pre_obs"], data["hopper_action"] = o, po, a
+        data["hopper_is_healthy"] = np.asarray(cls.is_healthy(f, o.copy()))
+        # step() semantics: B = 1 per call (np.sum(np.square(action)) has no axis, hopper.py:98)
+        data["hopper_reward_B1"] = np.stack([cls.get_batch_reward(f, o[i : i + 1].copy(), po[i : i + 1], a[i : i + 1])[0, 0] for i in range(B)])
+        data["hopper_terminal"] = np.asarray(cls.get_batch_terminal(f, o.copy()))
+        # the reference's own test inputs (test_hopper.py:9-13)
+        data["hopper_is_healthy_ones"] = np.asarray(cls.is_healthy(f, np.ones([128, 12])))
+        data["hopper_is_healthy_101"] = np.asarray(cls.is_healthy(f, np.ones([128, 12]) * 101))
+    # additive_gaussian_noise for B = 1: float, tuple and dict parameters
+    fm = NS(model=NS(jnt_type=[2, 2, 3, 3, 3, 3]))
+    q0 = np.array([[0.0, 1.25, 0.0, 0.0, 0.0, 0.0]])
+    for nm, prm in (("float", 5e-3), ("tuple", (0.01, 0.03)), ("dict0", {0: (0.1, 0.2)}), ("dict2", {2: (0.1, 0.2)})):
+        ps, vs = [], []
+        for seed in range(4):
+            np.random.seed(seed)
+            p, v = ref.me.EmeiMujocoEnv.additive_gaussian_noise(fm, q0.copy(), np.zeros((1, 6)), prm)
+            ps.append(p[0]), vs.append(v[0])
+        data[f"hopper_noise_{nm}_pos"], data[f"hopper_noise_{nm}_vel"] = np.asarray(ps), np.asarray(vs)
+    np.savez_compressed(os.path.join(out, "hopper_firstparty_golden.npz"), **data)
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -438,12 +485,13 @@ def main():
     c = gen_cartpole(ref, a.out)
     m = gen_mujoco_firstparty(ref, a.out)
     d = gen_dpend_firstparty(ref, a.out)
+    h = gen_hopper_firstparty(ref, a.out)
     env = ref.cp.CartPoleSwingUpEnv()
     o, _ = env.reset(seed=0)
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d))
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h))
 
 
 if __name__ == "__main__":

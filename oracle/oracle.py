@@ -20,7 +20,7 @@ IP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup
 
 def build(force=False):
     """Compile the oracle with gcc (no GPU needed)."""
-    srcs = [os.path.join(_HERE, f) for f in ("emei_oracle.c", "cheetah_oracle.c", "dpend_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("emei_oracle.c", "planar_oracle.c", "dpend_oracle.c", "integrators.h")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
@@ -151,6 +151,38 @@ def cartpole_step_numpy(variant, state, action, freq_rate=1, dt=0.02):
     return y, rew, term
 
 
+# --------------------------------------------------------------------------- integrator / noise options
+INTEGRATORS = {"euler": 0, "semi_implicit_euler": 1, "rk4": 2}
+
+
+class Opts(C.Structure):
+    """oracle_opts_t (integrators.h)."""
+
+    _fields_ = [("integrator", C.c_int32), ("shared", C.c_int32), ("obs_pos", C.c_float), ("obs_vel", C.c_float),
+                ("seed", C.c_uint64), ("env_offset", C.c_uint64), ("episode", C.c_uint32), ("step_index", C.c_uint32)]
+
+
+def opts(integrator="euler", obs_noise=0.0, shared=False, seed=0, env_offset=0, episode=0, step_index=0):
+    """Options of the *_step functions: integrator (mujoco_env.py:70-79) and per-substep observation noise
+    (:98-104) drawn from the device's counter-based stream at (seed, env, episode, step_index)."""
+    p, v = (obs_noise if isinstance(obs_noise, (tuple, list)) else (obs_noise, obs_noise))
+    return Opts(INTEGRATORS[integrator], int(bool(shared)), float(p), float(v), int(seed), int(env_offset), int(episode),
+                int(step_index))
+
+
+def _o(o):
+    return C.byref(o) if o is not None else None
+
+
+def body_init(seed, env, episode, nv, sigma_pos, sigma_vel=None, shared=False):
+    """Device reset of a MuJoCo-backed body: zeros + Gaussian noise -> float64 [2*nv] = (qpos, qvel)."""
+    out = np.empty(2 * nv)
+    lib().emei_oracle_body_init(C.c_uint64(int(seed)), C.c_uint64(int(env)), C.c_uint32(int(episode)), C.c_int(nv),
+                                C.c_float(sigma_pos), C.c_float(sigma_pos if sigma_vel is None else sigma_vel),
+                                C.c_int(int(bool(shared))), _p(out, C.c_double))
+    return out
+
+
 # --------------------------------------------------------------------------- InvertedPendulum (C)
 class IPModel(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
@@ -165,7 +197,7 @@ def ip_model():
     return m
 
 
-def ip_step(variant, state, action, freq_rate=1, dt=0.02):
+def ip_step(variant, state, action, freq_rate=1, dt=0.02, opt=None):
     """state [n,4]=(x, theta_unwrapped, v, omega) float64 -> (next_state, obs(wrapped), reward, terminal)."""
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
     n = st.shape[0]
@@ -173,8 +205,9 @@ def ip_step(variant, state, action, freq_rate=1, dt=0.02):
     obs = np.empty((n, 4))
     rew = np.empty(n)
     term = np.empty(n, np.uint8)
-    lib().emei_oracle_ip_step(C.c_int(IP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
-                              _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    lib().emei_oracle_ip_step_ex(C.c_int(IP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+                                 _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double),
+                                 _p(term, C.c_uint8), _o(opt))
     return st, obs, rew, term.astype(bool)
 
 
@@ -200,15 +233,15 @@ def ip_wrap(theta):
 
 
 # --------------------------------------------------------------------------- HalfCheetah-style body (C)
-def cheetah_step(state, action, freq_rate=4, dt=0.002):
+def cheetah_step(state, action, freq_rate=4, dt=0.002, opt=None):
     """state [n,18] = (qpos, qvel) float64 (copied), action [n,6] -> (next_state, reward, terminal)."""
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 18)
     n = st.shape[0]
     act = np.ascontiguousarray(action, dtype=np.float64).reshape(n, 6)
     rew = np.empty(n)
     term = np.empty(n, np.uint8)
-    lib().cheetah_oracle_step(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
-                              _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    lib().cheetah_oracle_step_ex(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
+                                 _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt))
     return st, rew, term.astype(bool)
 
 
@@ -240,11 +273,65 @@ def cheetah_inertia(q, v):
     return M, b, e.value
 
 
+def planar_inertia(body, q, v):
+    """(M [nv,nv], bias [nv], energy) of the planar-tree oracle; body "cheetah" (nv 9) or "hopper" (nv 6)."""
+    nv = {"cheetah": 9, "hopper": 6}[body]
+    q = np.ascontiguousarray(q, np.float64).reshape(nv)
+    v = np.ascontiguousarray(v, np.float64).reshape(nv)
+    M = np.empty((nv, nv))
+    b = np.empty(nv)
+    e = C.c_double()
+    lib().planar_oracle_inertia(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(v, C.c_double),
+                                _p(M, C.c_double), _p(b, C.c_double), C.byref(e))
+    return M, b, e.value
+
+
+def planar_geometry(body, q):
+    """(body masses [nb], world centres of the capsule end spheres [ng,2,2]) at configuration q."""
+    nb, ng, nv = {"cheetah": (7, 8, 9), "hopper": (4, 4, 6)}[body]
+    q = np.ascontiguousarray(q, np.float64).reshape(nv)
+    mass = np.empty(nb)
+    ends = np.empty((ng, 2, 2))
+    lib().planar_oracle_geometry(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(mass, C.c_double), _p(ends, C.c_double))
+    return mass, ends
+
+
+# --------------------------------------------------------------------------- Hopper (C)
+def hopper_step(state, action, freq_rate=4, dt=0.002, opt=None):
+    """state [n,12] = (qpos, qvel) float64 (copied), action [n,3] -> (next_state, reward, terminal).
+    The reference's default integrator for this env is "rk4" (hopper.py:22): pass opt=opts("rk4")."""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 12)
+    n = st.shape[0]
+    act = np.ascontiguousarray(action, dtype=np.float64).reshape(n, 3)
+    rew = np.empty(n)
+    term = np.empty(n, np.uint8)
+    lib().hopper_oracle_step_ex(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
+                                _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt))
+    return st, rew, term.astype(bool)
+
+
+def hopper_reward(obs, pre_obs, act, dt_env):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 12)
+    pre = np.ascontiguousarray(pre_obs, np.float64).reshape(-1, 12)
+    a = np.ascontiguousarray(act, np.float64).reshape(-1, 3)
+    out = np.empty(len(obs))
+    lib().hopper_oracle_reward(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
+                               C.c_double(dt_env), _p(out, C.c_double))
+    return out
+
+
+def hopper_is_healthy(obs):
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 12)
+    out = np.empty(len(obs), np.uint8)
+    lib().hopper_oracle_is_healthy(C.c_int64(len(obs)), _p(obs, C.c_double), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
 # --------------------------------------------------------------------------- InvertedDoublePendulum (C)
 DP_VARIANTS = {"rebound_balancing": 0, "boundary_balancing": 1, "rebound_swingup": 2, "boundary_swingup": 3}
 
 
-def dpend_step(variant, state, action, freq_rate=1, dt=0.02):
+def dpend_step(variant, state, action, freq_rate=1, dt=0.02, opt=None):
     """state [n,6] = (x, th1, th2, v, w1, w2) float64 -> (next_state, obs (quirk-wrapped), reward, terminal)."""
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 6)
     n = st.shape[0]
@@ -252,8 +339,9 @@ def dpend_step(variant, state, action, freq_rate=1, dt=0.02):
     obs = np.empty((n, 6))
     rew = np.empty(n)
     term = np.empty(n, np.uint8)
-    lib().dpend_oracle_step(C.c_int(DP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
-                            _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8))
+    lib().dpend_oracle_step_ex(C.c_int(DP_VARIANTS[variant]), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+                               _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double),
+                               _p(term, C.c_uint8), _o(opt))
     return st, obs, rew, term.astype(bool)
 
 

@@ -1,0 +1,479 @@
+/*
+ * planar_oracle.c — CPU restatement (float64) of the planar articulated bodies the reference steps
+ * with MuJoCo: the HalfCheetah-style body (emei/envs/mujoco/half_cheetah.py, assets/half_cheetah.xml)
+ * and the Hopper (emei/envs/mujoco/hopper.py, assets/hopper.xml).
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT (same rules as emei_oracle.c).
+ *
+ * PARITY UNPINNED for the dynamics: the reference steps these bodies with the third-party `mujoco`
+ * package (emei/envs/mujoco/mujoco_env.py:86-109; requirements/main.txt:7, "mujoco >= 2.2.0", not
+ * vendored, absent from the image).  This file restates, for a planar kinematic tree (slide-x,
+ * slide-z, hinge root + hinge children) described by a table, MuJoCo's published pipeline with the
+ * algorithms MuJoCo itself uses — inertia-from-geom (with settotalmass where the xml asks for it),
+ * recursive Newton-Euler for the bias forces, unit-acceleration RNE columns for the joint-space
+ * inertia, spring/damper passive forces, armature, Euler with implicit joint damping or RK4, soft
+ * constraints with solref/solimp impedance — combined with emei's integrator switch
+ * (mujoco_env.py:70-79,94-97,189-191; integrators.h).  One documented simplification: the
+ * constraint forces (joint limits, capsule/floor contacts with friction) are obtained by ONE
+ * fixed-order Gauss-Seidel sweep over the active constraints (limits first, then contact points in
+ * geom order; normal then tangent inside a contact) with regulariser R = (1-d)/d * A_ii, instead of
+ * MuJoCo's converged Newton solve with pyramidal cones.  The HIP kernels implement the same models
+ * with a different formulation (absolute-angle closed forms, emei_amd/csrc/cheetah_model.h and
+ * hopper_model.h), so kernel-vs-oracle agreement checks both.
+ *
+ * First-party pieces (pinned by tests/golden/mujoco_firstparty_golden.npz and
+ * hopper_firstparty_golden.npz): reward and terminal (half_cheetah.py:59-67; hopper.py:79-106), the
+ * Euler position rule, obs = concat(qpos, qvel).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "integrators.h"
+
+#define EXPORT __attribute__((visibility("default")))
+/* table capacities; cheetah: 7 bodies / 9 dof / 8 geoms / 6 actuators, hopper: 4 / 6 / 4 / 3 */
+#define NB 7
+#define NV 9
+#define NG 8
+#define NU 6
+
+typedef struct { double x, z; } v2;
+static inline v2 V(double x, double z) { v2 r = {x, z}; return r; }
+static inline v2 add(v2 a, v2 b) { return V(a.x + b.x, a.z + b.z); }
+static inline v2 sub(v2 a, v2 b) { return V(a.x - b.x, a.z - b.z); }
+static inline v2 scl(double s, v2 a) { return V(s * a.x, s * a.z); }
+static inline double dot(v2 a, v2 b) { return a.x * b.x + a.z * b.z; }
+/* rotation about +y by phi (MuJoCo hinge axis "0 1 0"): x' = x c + z s, z' = -x s + z c */
+static inline v2 rot(double phi, v2 a) { double c = cos(phi), s = sin(phi); return V(a.x * c + a.z * s, -a.x * s + a.z * c); }
+/* d/dphi of rot(phi, a) for the rotated vector v: (v.z, -v.x) */
+static inline v2 perp(v2 v) { return V(v.z, -v.x); }
+
+typedef struct {
+    int nb, nv, ng, nu;      /* bodies, dofs (= 2 + nb: rootx, rootz, then one hinge per body in body order), geoms, actuators */
+    int parent[NB];          /* parent body, -1 = world */
+    v2 body_pos[NB];         /* body origin (= its joint anchor) in the parent frame; root: world */
+    double hinge_sign[NB];   /* +1: hinge axis +y, -1: axis -y (hopper.xml:21,25,29) */
+    double z_ref;            /* `ref` of the rootz slide (hopper.xml:16): world z = body_pos.z + q[1] - z_ref */
+    double mass[NB], inertia[NB];
+    v2 com[NB];              /* centre of mass in the body frame */
+    /* capsule geoms for contact: end-sphere centres in the body frame, radius, pair friction with the floor */
+    int geom_body[NG];
+    v2 geom_end[NG][2];
+    double geom_radius[NG], geom_friction[NG];
+    double contact_margin;
+    double stiffness[NV], damping[NV], armature[NV], range_lo[NV], range_hi[NV];
+    int limited[NV];
+    int act_dof[NU];
+    double gear[NU];
+    double gravity;
+    /* solref / solimp: contacts and joint limits */
+    double c_tc, c_dr, c_dmin, c_dmax, c_width;
+    double l_tc, l_dr, l_dmin, l_dmax, l_width;
+} planar_model_t;
+typedef planar_model_t cheetah_model_t;
+
+static double capsule_mass(double rho, double r, double half) {
+    return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r);
+}
+static double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+
+/* a capsule given by centre, rotation `ang` about y of the default +z axis, half-length */
+static void capsule_ends(v2 centre, double ang, double half, v2 out[2]) {
+    v2 axis = rot(ang, V(0, 1));
+    out[0] = sub(centre, scl(half, axis));
+    out[1] = add(centre, scl(half, axis));
+}
+
+/* mass / com / inertia of every body from its capsule geoms (inertiafromgeom, density rho) */
+typedef struct { int body; v2 c; double ang, half, r; } geom_spec_t;
+static double bodies_from_geoms(planar_model_t* m, const geom_spec_t* g, double rho) {
+    double gm[NG], gi[NG], total = 0;
+    for (int k = 0; k < m->ng; ++k) {
+        gm[k] = capsule_mass(rho, g[k].r, g[k].half);
+        gi[k] = capsule_inertia_perp(rho, g[k].r, g[k].half);
+        m->geom_body[k] = g[k].body;
+        m->geom_radius[k] = g[k].r;
+        capsule_ends(g[k].c, g[k].ang, g[k].half, m->geom_end[k]);
+        total += gm[k];
+    }
+    for (int b = 0; b < m->nb; ++b) { /* parallel axis over the body's geoms */
+        double mb = 0; v2 c = V(0, 0);
+        for (int k = 0; k < m->ng; ++k) if (g[k].body == b) { mb += gm[k]; c = add(c, scl(gm[k], g[k].c)); }
+        c = scl(1.0 / mb, c);
+        double I = 0;
+        for (int k = 0; k < m->ng; ++k) if (g[k].body == b) { v2 d = sub(g[k].c, c); I += gi[k] + gm[k] * dot(d, d); }
+        m->mass[b] = mb, m->com[b] = c, m->inertia[b] = I;
+    }
+    return total;
+}
+
+/* assets/half_cheetah.xml: bodies torso, bthigh, bshin, bfoot, fthigh, fshin, ffoot (:62-88); dofs
+ * rootx, rootz, rooty, bthigh, bshin, bfoot, fthigh, fshin, ffoot; capsule geoms torso, head, 6 legs */
+EXPORT void cheetah_oracle_model(planar_model_t* m) {
+    memset(m, 0, sizeof(*m));
+    m->nb = 7, m->nv = 9, m->ng = 8, m->nu = 6;
+    const double r = 0.046, rho = 1000.0;
+    const int parent[7] = {-1, 0, 1, 2, 0, 4, 5};
+    const v2 bpos[7] = {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}};
+    memcpy(m->parent, parent, sizeof(parent));
+    memcpy(m->body_pos, bpos, sizeof(bpos));
+    for (int b = 0; b < 7; ++b) m->hinge_sign[b] = 1.0;
+    /* geoms: body, centre, angle about y, half-length, radius */
+    const geom_spec_t g[8] = {
+        {0, {0, 0}, M_PI / 2, 0.5, r},            /* torso: fromto (-.5,0,0)-(.5,0,0): axis along +x = z rotated by +pi/2 */
+        {0, {0.6, 0.1}, 0.87, 0.15, r},           /* head */
+        {1, {0.1, -0.13}, -3.8, 0.145, r},        /* bthigh */
+        {2, {-0.14, -0.07}, -2.03, 0.15, r},      /* bshin */
+        {3, {0.03, -0.097}, -0.27, 0.094, r},     /* bfoot */
+        {4, {-0.07, -0.12}, 0.52, 0.133, r},      /* fthigh */
+        {5, {0.065, -0.09}, -0.6, 0.106, r},      /* fshin */
+        {6, {0.045, -0.07}, -0.6, 0.07, r},       /* ffoot */
+    };
+    double total = bodies_from_geoms(m, g, rho);
+    double s = 14.0 / total; /* settotalmass (xml:35): masses and inertias scale together */
+    for (int b = 0; b < 7; ++b) m->mass[b] *= s, m->inertia[b] *= s;
+    const double stiff[6] = {240, 180, 120, 180, 120, 60}, damp[6] = {6, 4.5, 3, 4.5, 3, 1.5};
+    const double lo[6] = {-0.52, -0.785, -0.4, -1.0, -1.2, -0.5}, hi[6] = {1.05, 0.785, 0.785, 0.7, 0.87, 0.5};
+    const double gear[6] = {120, 90, 60, 120, 60, 30};
+    for (int k = 0; k < 6; ++k) {
+        m->stiffness[3 + k] = stiff[k], m->damping[3 + k] = damp[k], m->armature[3 + k] = 0.1;
+        m->range_lo[3 + k] = lo[k], m->range_hi[3 + k] = hi[k], m->limited[3 + k] = 1;
+        m->gear[k] = gear[k], m->act_dof[k] = 3 + k;
+    }
+    for (int k = 0; k < 8; ++k) m->geom_friction[k] = 0.4; /* default geom friction .4 (xml:38), floor the same */
+    m->gravity = 9.81;
+    m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.0, m->c_dmax = 0.8, m->c_width = 0.01;
+    m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.0, m->l_dmax = 0.8, m->l_width = 0.03;
+}
+EXPORT int cheetah_oracle_model_size(void) { return (int)sizeof(planar_model_t); }
+
+/* assets/hopper.xml (coordinate="global", angles in degrees): bodies torso, thigh, leg, foot; dofs
+ * rootx, rootz (ref 1.25), rooty, thigh, leg, foot; the three leg hinges turn about -y (:21,25,29).
+ * Body origins are placed at the joint anchors (world, at qpos0): torso (0,1.25) :17; thigh (0,1.05)
+ * :21; leg (0,0.6) :25; foot (0,0.1) :29.  Capsules: torso r .05 (0,1.45)-(0,1.05) :18; thigh r .05
+ * (0,1.05)-(0,.6) :22; leg r .04 (0,.6)-(0,.1) :26; foot r .06 (-.13,.1)-(.26,.1) :30.  Default
+ * density 1000, no settotalmass.  Joints: armature 1, damping 1, limited (:5), root joints 0/0/free
+ * (:15-17); ranges -150..0, -150..0, -45..45 deg; motors gear 200, ctrlrange +-1 (:37-39).
+ * Contacts: geom solref (.02 1), solimp (.8 .8 .01), margin .001 (:6); pair friction = max(floor 1
+ * (MuJoCo default, :13 sets none), geom): .9 -> 1 for torso/thigh/leg, 2 for the foot. */
+EXPORT void hopper_oracle_model(planar_model_t* m) {
+    memset(m, 0, sizeof(*m));
+    m->nb = 4, m->nv = 6, m->ng = 4, m->nu = 3;
+    const double rho = 1000.0, deg = M_PI / 180.0;
+    const int parent[4] = {-1, 0, 1, 2};
+    const v2 bpos[4] = {{0, 1.25}, {0, -0.2}, {0, -0.45}, {0, -0.5}};
+    memcpy(m->parent, parent, sizeof(parent));
+    memcpy(m->body_pos, bpos, sizeof(bpos));
+    m->hinge_sign[0] = 1.0, m->hinge_sign[1] = m->hinge_sign[2] = m->hinge_sign[3] = -1.0;
+    m->z_ref = 1.25;
+    const geom_spec_t g[4] = {
+        {0, {0, 0}, 0.0, 0.2, 0.05},             /* torso: centre (0,1.25) = the body origin, axis z */
+        {1, {0, -0.225}, 0.0, 0.225, 0.05},      /* thigh: centre (0,.825) */
+        {2, {0, -0.25}, 0.0, 0.25, 0.04},        /* leg: centre (0,.35) */
+        {3, {0.065, 0}, M_PI / 2, 0.195, 0.06},  /* foot: centre (.065,.1), axis x */
+    };
+    bodies_from_geoms(m, g, rho);
+    const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};
+    for (int k = 0; k < 3; ++k) {
+        m->damping[3 + k] = 1.0, m->armature[3 + k] = 1.0;
+        m->range_lo[3 + k] = lo[k], m->range_hi[3 + k] = hi[k], m->limited[3 + k] = 1;
+        m->gear[k] = 200.0, m->act_dof[k] = 3 + k;
+    }
+    m->geom_friction[0] = m->geom_friction[1] = m->geom_friction[2] = 1.0, m->geom_friction[3] = 2.0;
+    m->contact_margin = 0.001;
+    m->gravity = 9.81;
+    m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.8, m->c_dmax = 0.8, m->c_width = 0.01;
+    m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.9, m->l_dmax = 0.95, m->l_width = 0.001; /* MuJoCo joint defaults */
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * kinematics: absolute angle, origin and com of every body */
+typedef struct { double phi[NB]; v2 org[NB], com[NB]; } kin_t;
+
+/* dof of the hinge that moves body b relative to its parent (root body: rooty = 2) */
+static inline int hinge_dof(int b) { return 2 + b; }
+
+static void kinematics(const planar_model_t* m, const double* q, kin_t* k) {
+    for (int b = 0; b < m->nb; ++b) {
+        int p = m->parent[b];
+        if (p < 0) {
+            k->phi[b] = m->hinge_sign[b] * q[2];
+            k->org[b] = V(m->body_pos[b].x + q[0], m->body_pos[b].z + q[1] - m->z_ref);
+        } else {
+            k->phi[b] = k->phi[p] + m->hinge_sign[b] * q[hinge_dof(b)];
+            k->org[b] = add(k->org[p], rot(k->phi[p], m->body_pos[b]));
+        }
+        k->com[b] = add(k->org[b], rot(k->phi[b], m->com[b]));
+    }
+}
+
+/* Recursive Newton-Euler (the algorithm behind mj_rne): generalized forces that produce
+ * accelerations qdd at (q, qd); with qdd = 0 this is the bias vector c(q, qd) (+ gravity). */
+static void rnea(const planar_model_t* m, const kin_t* k, const double* qd, const double* qdd, double grav, double* tau) {
+    double w[NB], al[NB];
+    v2 vo[NB], ao[NB], f[NB];
+    double n[NB]; /* moment about the body origin accumulated from the subtree */
+    for (int b = 0; b < m->nb; ++b) {
+        int p = m->parent[b];
+        double sg = m->hinge_sign[b];
+        if (p < 0) {
+            w[b] = sg * qd[2], al[b] = sg * qdd[2];
+            vo[b] = V(qd[0], qd[1]);
+            ao[b] = V(qdd[0], qdd[1] + grav); /* gravity as an upward acceleration of the base */
+        } else {
+            v2 d = sub(k->org[b], k->org[p]);
+            w[b] = w[p] + sg * qd[hinge_dof(b)];
+            al[b] = al[p] + sg * qdd[hinge_dof(b)];
+            vo[b] = add(vo[p], scl(w[p], perp(d)));
+            ao[b] = add(ao[p], add(scl(al[p], perp(d)), scl(-w[p] * w[p], d)));
+        }
+        v2 rc = sub(k->com[b], k->org[b]);
+        v2 ac = add(ao[b], add(scl(al[b], perp(rc)), scl(-w[b] * w[b], rc)));
+        f[b] = scl(m->mass[b], ac);
+        /* moment about the body origin: I*alpha + rc x f  (planar: generalized torque of f at offset rc = f . perp(rc)) */
+        n[b] = m->inertia[b] * al[b] + dot(f[b], perp(rc));
+    }
+    for (int b = m->nb - 1; b >= 0; --b) {
+        int p = m->parent[b];
+        tau[hinge_dof(b)] = m->hinge_sign[b] * n[b];
+        if (p >= 0) {
+            v2 d = sub(k->org[b], k->org[p]);
+            n[p] += n[b] + dot(f[b], perp(d));
+            f[p] = add(f[p], f[b]);
+        } else {
+            tau[0] = f[b].x, tau[1] = f[b].z;
+        }
+    }
+}
+
+/* Jacobian (2 x nv) of a world point attached to body b */
+static void point_jacobian(const planar_model_t* m, const kin_t* k, int b, v2 p, double Jx[NV], double Jz[NV]) {
+    memset(Jx, 0, NV * sizeof(double));
+    memset(Jz, 0, NV * sizeof(double));
+    Jx[0] = 1, Jz[1] = 1;
+    for (int a = b; a >= 0; a = m->parent[a]) {
+        v2 d = scl(m->hinge_sign[a], perp(sub(p, k->org[a])));
+        Jx[hinge_dof(a)] = d.x, Jz[hinge_dof(a)] = d.z;
+    }
+}
+
+/* dense LDL^T of a symmetric positive definite n x n matrix (in place: L below the diagonal, D on it) */
+static void ldl_factor(int n, double A[NV][NV]) {
+    for (int j = 0; j < n; ++j) {
+        for (int k = 0; k < j; ++k) A[j][j] -= A[j][k] * A[j][k] * A[k][k];
+        for (int i = j + 1; i < n; ++i) {
+            for (int k = 0; k < j; ++k) A[i][j] -= A[i][k] * A[j][k] * A[k][k];
+            A[i][j] /= A[j][j];
+        }
+    }
+}
+static void ldl_solve(int n, const double A[NV][NV], double* x) {
+    for (int i = 0; i < n; ++i) for (int k = 0; k < i; ++k) x[i] -= A[i][k] * x[k];
+    for (int i = 0; i < n; ++i) x[i] /= A[i][i];
+    for (int i = n - 1; i >= 0; --i) for (int k = i + 1; k < n; ++k) x[i] -= A[k][i] * x[k];
+}
+
+static double impedance(double dist, double dmin, double dmax, double width) {
+    double x = fabs(dist) / width;
+    double y = x >= 1 ? 1.0 : (x <= 0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x)); /* midpoint .5, power 2 */
+    double d = dmin + y * (dmax - dmin);
+    return d < 1e-4 ? 1e-4 : (d > 0.9999 ? 0.9999 : d); /* mjMINIMP, mjMAXIMP */
+}
+
+/* forward dynamics (mj_forward): qacc at (q, v).  hd = dt for MuJoCo's Euler (implicit joint damping:
+ * (M + h D) qacc = f), 0 for RK4. */
+static void planar_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc) {
+    const planar_model_t* m = (const planar_model_t*)ctx;
+    const int nv = m->nv;
+    kin_t k;
+    kinematics(m, q, &k);
+    double zero[NV] = {0}, bias[NV], M[NV][NV];
+    rnea(m, &k, v, zero, m->gravity, bias);
+    for (int c = 0; c < nv; ++c) { /* inertia column c = RNE with unit acceleration, no velocity, no gravity */
+        double e[NV] = {0}, col[NV];
+        e[c] = 1;
+        rnea(m, &k, zero, e, 0.0, col);
+        for (int r = 0; r < nv; ++r) M[r][c] = col[r];
+    }
+    double f[NV];
+    for (int i = 0; i < nv; ++i) {
+        f[i] = -bias[i] - m->stiffness[i] * q[i] - m->damping[i] * v[i]; /* passive: spring to 0, damper */
+        M[i][i] += m->armature[i] + hd * m->damping[i];                  /* Euler with implicit damping: M + h D */
+    }
+    for (int a = 0; a < m->nu; ++a) {
+        double c = ctrl[a] < -1 ? -1 : (ctrl[a] > 1 ? 1 : ctrl[a]); /* ctrllimited, ctrlrange +-1 */
+        f[m->act_dof[a]] += m->gear[a] * c;
+    }
+    ldl_factor(nv, M);
+    memcpy(acc, f, nv * sizeof(double));
+    ldl_solve(nv, M, acc); /* unconstrained acceleration */
+
+    /* --- soft constraints, one Gauss-Seidel sweep -------------------------------------------- */
+    double l_tc = m->l_tc < 2 * dt ? 2 * dt : m->l_tc, c_tc = m->c_tc < 2 * dt ? 2 * dt : m->c_tc; /* refsafe */
+    for (int i = 3; i < nv; ++i) { /* joint limits (mjCNSTR_LIMIT_JOINT) */
+        double dist, J;
+        if (!m->limited[i]) continue;
+        if (q[i] - m->range_lo[i] < 0) dist = q[i] - m->range_lo[i], J = 1;
+        else if (m->range_hi[i] - q[i] < 0) dist = m->range_hi[i] - q[i], J = -1;
+        else continue;
+        double w[NV] = {0};
+        w[i] = J;
+        ldl_solve(nv, M, w);
+        double A = J * w[i];
+        double imp = impedance(dist, m->l_dmin, m->l_dmax, m->l_width);
+        double K = 1 / (m->l_dmax * m->l_dmax * l_tc * l_tc * m->l_dr * m->l_dr), B = 2 / (m->l_dmax * l_tc);
+        double aref = -B * (J * v[i]) - K * imp * dist;
+        double R = (1 - imp) / imp * A;
+        double force = (aref - J * acc[i]) / (A + R);
+        if (force > 0) for (int r = 0; r < nv; ++r) acc[r] += w[r] * force;
+    }
+    double cK = 1 / (m->c_dmax * m->c_dmax * c_tc * c_tc * m->c_dr * m->c_dr), cB = 2 / (m->c_dmax * c_tc);
+    for (int g = 0; g < m->ng; ++g) { /* capsule end spheres against the floor plane z = 0 */
+        int b = m->geom_body[g];
+        for (int e = 0; e < 2; ++e) {
+            v2 s = add(k.org[b], rot(k.phi[b], m->geom_end[g][e]));
+            double dist = s.z - m->geom_radius[g];
+            if (!(dist < m->contact_margin)) continue;
+            v2 p = V(s.x, 0.5 * dist); /* MuJoCo places the contact midway between the surfaces */
+            double Jx[NV], Jz[NV], wx[NV], wz[NV];
+            point_jacobian(m, &k, b, p, Jx, Jz);
+            memcpy(wx, Jx, sizeof(wx));
+            memcpy(wz, Jz, sizeof(wz));
+            ldl_solve(nv, M, wx);
+            ldl_solve(nv, M, wz);
+            double Ann = 0, Att = 0, Atn = 0, an = 0, at = 0, vn = 0, vt = 0;
+            for (int r = 0; r < nv; ++r) {
+                Ann += Jz[r] * wz[r], Att += Jx[r] * wx[r], Atn += Jx[r] * wz[r];
+                an += Jz[r] * acc[r], at += Jx[r] * acc[r];
+                vn += Jz[r] * v[r], vt += Jx[r] * v[r];
+            }
+            double pos = dist - m->contact_margin;
+            double imp = impedance(pos, m->c_dmin, m->c_dmax, m->c_width);
+            double Rn = (1 - imp) / imp * Ann, Rt = (1 - imp) / imp * Att;
+            double fn = (-cB * vn - cK * imp * pos - an) / (Ann + Rn);
+            if (!(fn > 0)) continue;
+            double ft = (-cB * vt - at - Atn * fn) / (Att + Rt);
+            double lim = m->geom_friction[g] * fn;
+            ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
+            for (int r = 0; r < nv; ++r) acc[r] += wz[r] * fn + wx[r] * ft;
+        }
+    }
+}
+
+/* half_cheetah.py:59-63 with step() semantics (one env per call) and :65-67 */
+static double cheetah_reward(const double* obs, const double* pre_obs, const double* act, double dt_env) {
+    double cost = 0;
+    for (int a = 0; a < 6; ++a) cost += act[a] * act[a];
+    return 1.0 * (obs[0] - pre_obs[0]) / dt_env - 0.1 * cost;
+}
+static uint8_t cheetah_terminal(const double* obs) {
+    int fin = 1;
+    for (int i = 0; i < 18; ++i) fin &= isfinite(obs[i]) != 0;
+    return (uint8_t)!fin;
+}
+
+/* mujoco_env.py:157-167 for a batch: state [n,18] = (qpos, qvel) in/out, action [n,6] */
+EXPORT void cheetah_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                   uint8_t* terminal, const oracle_opts_t* opts) {
+    planar_model_t m;
+    cheetah_oracle_model(&m);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double* s = state + 18 * i;
+        double pre[18];
+        memcpy(pre, s, sizeof(pre));
+        oracle_env_step(planar_accel, &m, 9, freq_rate, dt, opts, i, s, s + 9, action + 6 * i);
+        reward[i] = cheetah_reward(s, pre, action + 6 * i, dt * freq_rate);
+        terminal[i] = cheetah_terminal(s);
+    }
+}
+EXPORT void cheetah_oracle_step(int64_t n, int freq_rate, double dt, double* state, const double* action,
+                                double* reward, uint8_t* terminal) {
+    cheetah_oracle_step_ex(n, freq_rate, dt, state, action, reward, terminal, NULL);
+}
+
+EXPORT void cheetah_oracle_reward(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = cheetah_reward(obs + 18 * i, pre_obs + 18 * i, act + 6 * i, dt_env);
+}
+EXPORT void cheetah_oracle_terminal(int64_t n, const double* obs, uint8_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = cheetah_terminal(obs + 18 * i);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Hopper (hopper.py).  is_healthy (:79-93) as the reference EXECUTES it: np.logical_and(healthy_state,
+ * healthy_z, healthy_angle) passes healthy_angle as `out=`, so the result is healthy_state & healthy_z
+ * and the angle range never matters.  terminal = ~(is_healthy | terminate_when_unhealthy) (:104-106)
+ * is False for the default terminate_when_unhealthy = True; the healthy reward
+ * (is_healthy | True) * 1.0 (:99) is always 1.  Per-env control cost (step() semantics). */
+static int hopper_is_healthy(const double* obs) {
+    int st = 1;
+    for (int i = 2; i < 12; ++i) st &= (-100.0 < obs[i]) && (obs[i] < 100.0);
+    return st && (0.7 < obs[1]) && (obs[1] < INFINITY);
+}
+static double hopper_reward(const double* obs, const double* pre_obs, const double* act, double dt_env) {
+    double cost = 0;
+    for (int a = 0; a < 3; ++a) cost += act[a] * act[a];
+    return 1.0 + 1.0 * (obs[0] - pre_obs[0]) / dt_env - 1e-3 * cost;
+}
+EXPORT void hopper_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                  uint8_t* terminal, const oracle_opts_t* opts) {
+    planar_model_t m;
+    hopper_oracle_model(&m);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double* s = state + 12 * i;
+        double pre[12];
+        memcpy(pre, s, sizeof(pre));
+        oracle_env_step(planar_accel, &m, 6, freq_rate, dt, opts, i, s, s + 6, action + 3 * i);
+        reward[i] = hopper_reward(s, pre, action + 3 * i, dt * freq_rate);
+        terminal[i] = 0;
+    }
+}
+EXPORT void hopper_oracle_reward(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = hopper_reward(obs + 12 * i, pre_obs + 12 * i, act + 3 * i, dt_env);
+}
+EXPORT void hopper_oracle_is_healthy(int64_t n, const double* obs, uint8_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)hopper_is_healthy(obs + 12 * i);
+}
+
+/* diagnostics for the tests: mass matrix [nv,nv], bias and total mechanical energy at (q, v); body 0 = cheetah, 1 = hopper */
+EXPORT void planar_oracle_inertia(int body, const double* q, const double* v, double* M_out, double* bias_out, double* energy_out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    const int nv = m.nv;
+    kin_t k;
+    kinematics(&m, q, &k);
+    double zero[NV] = {0};
+    rnea(&m, &k, v, zero, m.gravity, bias_out);
+    for (int c = 0; c < nv; ++c) {
+        double e[NV] = {0}, col[NV];
+        e[c] = 1;
+        rnea(&m, &k, zero, e, 0.0, col);
+        for (int r = 0; r < nv; ++r) M_out[r * nv + c] = col[r];
+    }
+    double T = 0, U = 0;
+    for (int r = 0; r < nv; ++r) for (int c = 0; c < nv; ++c) T += 0.5 * v[r] * M_out[r * nv + c] * v[c];
+    for (int b = 0; b < m.nb; ++b) U += m.mass[b] * m.gravity * k.com[b].z;
+    for (int i = 0; i < nv; ++i) T += 0.5 * m.armature[i] * v[i] * v[i], U += 0.5 * m.stiffness[i] * q[i] * q[i];
+    *energy_out = T + U;
+}
+EXPORT void cheetah_oracle_inertia(const double* q, const double* v, double* M_out, double* bias_out, double* energy_out) {
+    planar_oracle_inertia(0, q, v, M_out, bias_out, energy_out);
+}
+/* body masses / world contact-sphere centres at q, for geometry checks in the tests */
+EXPORT void planar_oracle_geometry(int body, const double* q, double* mass_out, double* ends_out /* [ng][2][2] */) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    kin_t k;
+    kinematics(&m, q, &k);
+    for (int b = 0; b < m.nb; ++b) mass_out[b] = m.mass[b];
+    for (int g = 0; g < m.ng; ++g)
+        for (int e = 0; e < 2; ++e) {
+            v2 s = add(k.org[m.geom_body[g]], rot(k.phi[m.geom_body[g]], m.geom_end[g][e]));
+            ends_out[(g * 2 + e) * 2] = s.x, ends_out[(g * 2 + e) * 2 + 1] = s.z;
+        }
+}

@@ -25,6 +25,11 @@ def mujoco_golden():
     return np.load(os.path.join(GOLDEN, "mujoco_firstparty_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def hopper_golden():
+    return np.load(os.path.join(GOLDEN, "hopper_firstparty_golden.npz"))
+
+
 def rel_err(a, b, floor=1.0):
     """max |a-b| / max(|b|, floor) ignoring rows where both are NaN."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)

@@ -90,10 +90,17 @@ def test_spaces_and_registry():
     env = emei_amd.make("BoundaryInvertedPendulumBalancing-v0", freq_rate=4)
     assert env.max_episode_steps == 1000 and env.freq_rate == 4 and env.observation_space.shape == (4,)
     assert emei_amd.make("HalfCheetahRunning-v0").dt == pytest.approx(0.008)
+    assert emei_amd.spec("HopperRunning-v0")["max_episode_steps"] == 1000  # register_env.py:87-91
+    hop = emei_amd.make("HopperRunning-v0")
+    assert hop.integrator == "rk4" and hop.dt == pytest.approx(0.008) and hop.action_space.shape == (3,)  # hopper.py:20-22
     with pytest.raises(KeyError):
-        emei_amd.spec("Hopper-v0")
-    with pytest.raises(NotImplementedError):
-        emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator="rk4")
+        emei_amd.spec("Walker2dRunning-v0")  # registered by the reference, class never written (register_env.py:92-96)
+    with pytest.raises(NotImplementedError):  # mujoco_env.py:78-79
+        emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator="verlet")
+    for integ in ("euler", "semi_implicit_euler", "rk4"):
+        e = emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator=integ, obs_noise_params=(1e-3, 2e-3))
+        assert e.env_params_name == f"freq_rate=1&integrator={integ}&real_time_scale=0.02"  # mujoco_env.py:51
+    emei_amd.HopperRunningEnv(obs_noise_params={0: (0.1, 0.1)})  # the dict form of test_hopper.py:47
 
 
 def test_abi_library_exports_every_declared_symbol():
