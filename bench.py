@@ -35,6 +35,8 @@ WORKLOADS = {
                   desc="InvertedDoublePendulum forward-Euler, 262 144 parallel envs, freq_ratio=4 (SURVEY 8f rank 3)"),
     "cheetah": dict(env="HalfCheetahRunning", n=131072, freq_rate=4, dt=0.002, horizon=100,
                     desc="HalfCheetah-style body forward-Euler, 131 072 parallel envs (BASELINE configs[3])"),
+    "hopper": dict(env="HopperRunning", n=131072, freq_rate=4, dt=0.002, horizon=100, integrator="rk4",
+                   desc="Hopper, RK4 (the reference's default, hopper.py:20-22), 131 072 parallel envs (SURVEY 8f rank 4)"),
 }
 
 
@@ -79,6 +81,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
+    ap.add_argument("--integrator", default=None, choices=["euler", "semi_implicit_euler", "rk4"],
+                    help="MuJoCo-backed bodies only (mujoco_env.py:70-79); default: the workload's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
     a = ap.parse_args()
@@ -122,7 +126,8 @@ def main():
     T = a.horizon or w["horizon"]
     env = w["env"]
     sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
-                        rank=rank, world=world, device=local_rank, seed=0)
+                        rank=rank, world=world, device=local_rank, seed=0,
+                        integrator=a.integrator or w.get("integrator", "euler"))
     sr.make_synthetic_inputs()
 
     for _ in range(a.warmup):
@@ -171,7 +176,7 @@ def main():
         "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if a.precision == "ref" else "f32", "data": "synthetic",
         "config": {"workload": w["desc"], "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
-                   "real_time_scale": w["dt"], "api": "emei_rollout (one launch per horizon, device auto-reset)",
+                   "real_time_scale": w["dt"], "integrator": a.integrator or w.get("integrator", "euler"), "api": "emei_rollout (one launch per horizon, device auto-reset)",
                    "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
                    "obs_allgather": "final obs of each pass over RCCL" if world > 1 else "n/a (1 GPU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

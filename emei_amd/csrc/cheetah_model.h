@@ -23,6 +23,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "emei_device.h"
 
@@ -94,15 +95,24 @@ __device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
             if (nz(i, j)) A[i][j] *= invd[j];
     }
 }
-template <typename R>
-__device__ __forceinline__ void ldl_solve(const R (&A)[NV][NV], const R (&invd)[NV], R (&x)[NV]) {
+// Structural non-zeros of L^-1 J for a constraint whose Jacobian starts at coordinate FIRST (a link: its own
+// angle, its ancestors on the same leg, then torso, x, z): everything before FIRST and the other leg stay 0.
+__host__ __device__ constexpr bool in_pat(int first, int i) { return i >= 6 || (first < 6 && (i / 3) == (first / 3) && i >= first); }
+
+// y <- L^-1 y for a right-hand side with the pattern of FIRST (FIRST = 0 with every entry set: the dense case)
+template <int FIRST, bool DENSE, typename R>
+__device__ __forceinline__ void ldl_forward(const R (&A)[NV][NV], R (&y)[NV]) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+    for (int j = 0; j < NV; ++j) {
+        if (!(DENSE || in_pat(FIRST, j))) continue;
 #pragma unroll
         for (int i = j + 1; i < NV; ++i)
-            if (nz(i, j)) x[i] = fma_r(-A[i][j], x[j], x[i]);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) x[j] *= invd[j];
+            if (nz(i, j)) y[i] = fma_r(-A[i][j], y[j], y[i]);
+    }
+}
+// x <- L^-T x
+template <typename R>
+__device__ __forceinline__ void ldl_backward(const R (&A)[NV][NV], R (&x)[NV]) {
 #pragma unroll
     for (int j = NV - 1; j >= 0; --j)
 #pragma unroll
@@ -208,37 +218,48 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
         A[hi_][lo_] -= e;
     }
 
+    // M = L D L^T.  The acceleration is carried in "half-solved" form z = D^-1 L^-1 (f + sum J^T lambda):
+    // for a constraint row J with y = L^-1 J^T, J M^-1 J^T = y . D^-1 y and J acc = y . z, so a constraint costs
+    // one sparse forward substitution per row and no backward one; acc = L^-T z once at the end.
     R invd[NV];
     ldl_factor(A, invd);
-    R acc[NV];
+    R z[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = f[i];
-    ldl_solve(A, invd, acc);
+    for (int i = 0; i < NV; ++i) z[i] = f[i];
+    ldl_forward<0, true>(A, z);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] *= invd[i];
 
-    // ---- soft constraints, one Gauss-Seidel sweep (oracle/cheetah_oracle.c order) -----------------
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {  // joint limits on theta_k
+    // ---- soft constraints, one Gauss-Seidel sweep (oracle/planar_oracle.c order) -------------------
+    auto limit = [&](auto kc) __attribute__((always_inline)) {  // joint limit on theta_k
+        constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];  // child index < parent index
         const R th = q[3 + k];
         R dist = R(0), J = R(0);
         if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
         else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
         if (J != R(0)) {
-            R w[NV];
+            R y[NV], yd[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) w[i] = R(0);
-            w[jc[k]] = J, w[jp[k]] = -J;
-            ldl_solve(A, invd, w);
-            const R Aii = J * (w[jc[k]] - w[jp[k]]);
+            for (int i = 0; i < NV; ++i) y[i] = R(0);
+            y[C] = J, y[P] = -J;
+            ldl_forward<C, false>(A, y);
+            R Aii = R(0), acur = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_pat(C, i)) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
             const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = (R(1) - imp) / imp * Aii;
-            const R force = (aref - J * (acc[jc[k]] - acc[jp[k]])) / (Aii + Rr);
+            const R force = (aref - acur) / (Aii + Rr);
             if (force > R(0)) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) acc[i] = fma_r(w[i], force, acc[i]);
+                for (int i = 0; i < NV; ++i)
+                    if (in_pat(C, i)) z[i] = fma_r(yd[i], force, z[i]);
             }
         }
-    }
+    };
+    limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
+    limit(std::integral_constant<int, 3>{}), limit(std::integral_constant<int, 4>{}), limit(std::integral_constant<int, 5>{});
     // body origins (world) for the contact points
     const V2<R> o_t = {q[0], (R)m.z0 + q[1]};
     const V2<R> o_bt = {o_t.x + Dtb.x, o_t.z + Dtb.z}, o_bs = {o_bt.x + Dbt.x, o_bt.z + Dbt.z},
@@ -251,11 +272,12 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     for (int b = 0; b < 7; ++b) u[b] = om[b];
     u[P_X] = v[0], u[P_Z] = v[1];
 
-    // one capsule end sphere of a body against the floor: `LNK` = permuted link of the body, `ORG` its
-    // origin, CH0..CH2 = (link, rotated vector) of the ancestors on its chain (compile-time list)
-    auto contact = [&](int pt, int lnk, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
+    // one capsule end sphere of a body against the floor: LNK = permuted link of the body, `org` its origin,
+    // (a1,v1)..(a3,v3) = (link, rotated link vector) of the ancestors on its chain
+    auto contact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
                        __attribute__((always_inline)) {
-        const V2<R> e = rot(cs[lnk], sn[lnk], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
+        constexpr int LNK = decltype(lnk_c)::value;
+        const V2<R> e = rot(cs[LNK], sn[LNK], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
         const R sz_ = org.z + e.z;
         const R dist = sz_ - (R)m.radius;
         if (dist < R(0)) {
@@ -266,23 +288,25 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
             Jx[P_X] = R(1), Jz[P_Z] = R(1);
             // d p / d phi_j = perp(vector from link j's contribution): own link uses r, ancestors their link vector
-            Jx[lnk] = r.z, Jz[lnk] = -r.x;
-            // an ancestor link a contributes its rotated link vector (the part of the chain it carries)
+            Jx[LNK] = r.z, Jz[LNK] = -r.x;
             if (a1 >= 0) Jx[a1] = v1.z, Jz[a1] = -v1.x;
             if (a2 >= 0) Jx[a2] = v2.z, Jz[a2] = -v2.x;
             if (a3 >= 0) Jx[a3] = v3.z, Jz[a3] = -v3.x;
-            R wx[NV], wz[NV];
+            R vn = R(0), vt = R(0);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) wx[i] = Jx[i], wz[i] = Jz[i];
-            ldl_solve(A, invd, wx);
-            ldl_solve(A, invd, wz);
-            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0), vn = R(0), vt = R(0);
+            for (int i = 0; i < NV; ++i)
+                if (in_pat(LNK, i)) vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+            ldl_forward<LNK, false>(A, Jx);  // Jx, Jz now hold L^-1 J^T
+            ldl_forward<LNK, false>(A, Jz);
+            R dx[NV], dz[NV];
+            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                Ann = fma_r(Jz[i], wz[i], Ann), Att = fma_r(Jx[i], wx[i], Att), Atn = fma_r(Jx[i], wz[i], Atn);
-                an = fma_r(Jz[i], acc[i], an), at = fma_r(Jx[i], acc[i], at);
-                vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
-            }
+            for (int i = 0; i < NV; ++i)
+                if (in_pat(LNK, i)) {
+                    dx[i] = Jx[i] * invd[i], dz[i] = Jz[i] * invd[i];
+                    Ann = fma_r(Jz[i], dz[i], Ann), Att = fma_r(Jx[i], dx[i], Att), Atn = fma_r(Jx[i], dz[i], Atn);
+                    an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
+                }
             const R imp = impedance(dist, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
             const R k1 = (R(1) - imp) / imp;
             const R fn = (-(R)m.cB * vn - (R)m.cK * imp * dist - an) / (Ann + k1 * Ann);
@@ -291,28 +315,35 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 const R lim = (R)m.friction * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll
-                for (int i = 0; i < NV; ++i) acc[i] = fma_r(wz[i], fn, fma_r(wx[i], ft, acc[i]));
+                for (int i = 0; i < NV; ++i)
+                    if (in_pat(LNK, i)) z[i] = fma_r(dz[i], fn, fma_r(dx[i], ft, z[i]));
             }
         }
     };
     const V2<R> none = {R(0), R(0)};
+    using std::integral_constant;
     // geom order: torso(0,1) head(2,3) bthigh(4,5) bshin(6,7) bfoot(8,9) fthigh(10,11) fshin(12,13) ffoot(14,15)
-    contact(0, P_TORSO, o_t, -1, none, -1, none, -1, none);
-    contact(1, P_TORSO, o_t, -1, none, -1, none, -1, none);
-    contact(2, P_TORSO, o_t, -1, none, -1, none, -1, none);
-    contact(3, P_TORSO, o_t, -1, none, -1, none, -1, none);
-    contact(4, P_BTHIGH, o_bt, P_TORSO, Dtb, -1, none, -1, none);
-    contact(5, P_BTHIGH, o_bt, P_TORSO, Dtb, -1, none, -1, none);
-    contact(6, P_BSHIN, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
-    contact(7, P_BSHIN, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
-    contact(8, P_BFOOT, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
-    contact(9, P_BFOOT, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
-    contact(10, P_FTHIGH, o_ft, P_TORSO, Dtf, -1, none, -1, none);
-    contact(11, P_FTHIGH, o_ft, P_TORSO, Dtf, -1, none, -1, none);
-    contact(12, P_FSHIN, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
-    contact(13, P_FSHIN, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
-    contact(14, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
-    contact(15, P_FFOOT, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+    contact(0, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+    contact(1, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+    contact(2, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+    contact(3, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+    contact(4, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+    contact(5, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+    contact(6, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+    contact(7, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+    contact(8, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+    contact(9, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+    contact(10, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+    contact(11, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+    contact(12, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+    contact(13, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+    contact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+    contact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+
+    R acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = z[i];
+    ldl_backward(A, acc);
 
     // ---- back to joint coordinates
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[P_TORSO];

@@ -20,6 +20,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "cheetah_model.h"  // V2, rot, dot, dotperp, impedance
 #include "emei_device.h"
@@ -64,14 +65,18 @@ __device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
         for (int i = j + 1; i < NV; ++i) A[i][j] *= invd[j];
     }
 }
+// y <- L^-1 y for a right-hand side whose entries before FIRST are structurally zero (a constraint on
+// link FIRST touches its own angle, its ancestors' - the higher indices - and x, z)
+template <int FIRST, typename R>
+__device__ __forceinline__ void ldl_forward(const R (&A)[NV][NV], R (&y)[NV]) {
+#pragma unroll
+    for (int j = FIRST; j < NV; ++j)
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) y[i] = fma_r(-A[i][j], y[j], y[i]);
+}
+// x <- L^-T x
 template <typename R>
-__device__ __forceinline__ void ldl_solve(const R (&A)[NV][NV], const R (&invd)[NV], R (&x)[NV]) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int i = j + 1; i < NV; ++i) x[i] = fma_r(-A[i][j], x[j], x[i]);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) x[j] *= invd[j];
+__device__ __forceinline__ void ldl_backward(const R (&A)[NV][NV], R (&x)[NV]) {
 #pragma unroll
     for (int j = NV - 1; j >= 0; --j)
 #pragma unroll
@@ -137,36 +142,43 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
         A[jp[k]][jp[k]] += e;
         A[jp[k]][jc[k]] -= e;  // parent index > child index: lower triangle
     }
-    R invd[NV], acc[NV];
+    // M = L D L^T; the acceleration is carried as z = D^-1 L^-1 (f + sum J^T lambda) (see cheetah_model.h):
+    // a constraint row J costs one forward substitution y = L^-1 J^T (J M^-1 J^T = y . D^-1 y, J acc = y . z)
+    R invd[NV], z[NV];
     ldl_factor(A, invd);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = f[i];
-    ldl_solve(A, invd, acc);
+    for (int i = 0; i < NV; ++i) z[i] = f[i];
+    ldl_forward<0>(A, z);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] *= invd[i];
 
     // ---- soft constraints, one Gauss-Seidel sweep (oracle/planar_oracle.c order)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {  // joint limits on theta_k
+    auto limit = [&](auto kc) __attribute__((always_inline)) {  // joint limit on theta_k = phi_P - phi_C
+        constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];  // C < P
         const R th = q[3 + k];
         R dist = R(0), J = R(0);
         if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
         else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
         if (J != R(0)) {
-            R w[NV];
+            R y[NV], yd[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) w[i] = R(0);
-            w[jc[k]] = -J, w[jp[k]] = J;  // d theta_k / d phi
-            ldl_solve(A, invd, w);
-            const R Aii = J * (w[jp[k]] - w[jc[k]]);
+            for (int i = 0; i < NV; ++i) y[i] = R(0);
+            y[C] = -J, y[P] = J;
+            ldl_forward<C>(A, y);
+            R Aii = R(0), acur = R(0);
+#pragma unroll
+            for (int i = C; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
             const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = (R(1) - imp) / imp * Aii;
-            const R force = (aref - J * (acc[jp[k]] - acc[jc[k]])) / (Aii + Rr);
+            const R force = (aref - acur) / (Aii + Rr);
             if (force > R(0)) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) acc[i] = fma_r(w[i], force, acc[i]);
+                for (int i = C; i < NV; ++i) z[i] = fma_r(yd[i], force, z[i]);
             }
         }
-    }
+    };
+    limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
     // link origins (world): torso, then down the chain
     V2<R> org[NL];
     org[L_TORSO] = V2<R>{q[0], (R)m.z0 + q[1]};
@@ -177,34 +189,33 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
     for (int b = 0; b < NL; ++b) u[b] = om[b];
     u[P_X] = v[0], u[P_Z] = v[1];
-    constexpr int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
-#pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {  // capsule end spheres against the floor, geom order torso, thigh, leg, foot
-        const int gi = pt / 2, lnk = geom_link[gi];
-        const V2<R> e = rot(cs[lnk], sn[lnk], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
-        const R dist = org[lnk].z + e.z - (R)m.radius[gi];
+    // one capsule end sphere against the floor; geom order torso, thigh, leg, foot (two ends each)
+    auto contact = [&](auto pt_c) __attribute__((always_inline)) {
+        constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+        const V2<R> e = rot(cs[LNK], sn[LNK], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
+        const R dist = org[LNK].z + e.z - (R)m.radius[gi];
         if (dist < (R)m.margin) {
             // contact point midway between the surfaces: p = (s.x, dist/2); r = p - link origin
-            const V2<R> r = {e.x, R(0.5) * dist - org[lnk].z};
+            const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
             R Jx[NV], Jz[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
             Jx[P_X] = R(1), Jz[P_Z] = R(1);
-            Jx[lnk] = r.z, Jz[lnk] = -r.x;
+            Jx[LNK] = r.z, Jz[LNK] = -r.x;
 #pragma unroll
-            for (int a = 1; a < NL; ++a)  // every ancestor contributes perp(its link vector)
-                if (a > lnk) Jx[a] = D[a].z, Jz[a] = -D[a].x;
-            R wx[NV], wz[NV];
+            for (int a = LNK + 1; a < NL; ++a) Jx[a] = D[a].z, Jz[a] = -D[a].x;  // ancestors: perp(their link vector)
+            R vn = R(0), vt = R(0);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) wx[i] = Jx[i], wz[i] = Jz[i];
-            ldl_solve(A, invd, wx);
-            ldl_solve(A, invd, wz);
-            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0), vn = R(0), vt = R(0);
+            for (int i = LNK; i < NV; ++i) vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+            ldl_forward<LNK>(A, Jx);  // Jx, Jz now hold L^-1 J^T
+            ldl_forward<LNK>(A, Jz);
+            R dx[NV], dz[NV];
+            R Ann = R(0), Att = R(0), Atn = R(0), an = R(0), at = R(0);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                Ann = fma_r(Jz[i], wz[i], Ann), Att = fma_r(Jx[i], wx[i], Att), Atn = fma_r(Jx[i], wz[i], Atn);
-                an = fma_r(Jz[i], acc[i], an), at = fma_r(Jx[i], acc[i], at);
-                vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+            for (int i = LNK; i < NV; ++i) {
+                dx[i] = Jx[i] * invd[i], dz[i] = Jz[i] * invd[i];
+                Ann = fma_r(Jz[i], dz[i], Ann), Att = fma_r(Jx[i], dx[i], Att), Atn = fma_r(Jx[i], dz[i], Atn);
+                an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
             }
             const R pos = dist - (R)m.margin;
             const R imp = impedance(pos, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
@@ -215,10 +226,19 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 const R lim = (R)m.friction[gi] * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll
-                for (int i = 0; i < NV; ++i) acc[i] = fma_r(wz[i], fn, fma_r(wx[i], ft, acc[i]));
+                for (int i = LNK; i < NV; ++i) z[i] = fma_r(dz[i], fn, fma_r(dx[i], ft, z[i]));
             }
         }
-    }
+    };
+    using std::integral_constant;
+    contact(integral_constant<int, 0>{}), contact(integral_constant<int, 1>{}), contact(integral_constant<int, 2>{});
+    contact(integral_constant<int, 3>{}), contact(integral_constant<int, 4>{}), contact(integral_constant<int, 5>{});
+    contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
+    R acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = z[i];
+    ldl_backward(A, acc);
+
     // ---- back to joint coordinates
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[L_TORSO];
     qacc[3] = acc[L_TORSO] - acc[L_THIGH], qacc[4] = acc[L_THIGH] - acc[L_LEG], qacc[5] = acc[L_LEG] - acc[L_FOOT];

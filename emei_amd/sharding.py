@@ -50,8 +50,8 @@ def synthetic_init_state(env, n_global, lo, hi, seed=0):
         return (rng.standard_normal((n_global, 6)) * 5e-3)[lo:hi]
     if "InvertedPendulum" in env:
         return (rng.standard_normal((n_global, 4)) * 5e-3)[lo:hi]  # mujoco_env.py:31,137-140
-    if env == "HalfCheetahRunning":
-        return None  # device reset (init_qpos + sigma*N(0,1)), see cheetah.hip
+    if env in ("HalfCheetahRunning", "HopperRunning"):
+        return None  # device reset (init_qpos + sigma*N(0,1)), body_kernels.h:body_init
     raise ValueError(env)
 
 
@@ -71,7 +71,7 @@ class ShardedRollout:
     MAX_EPISODE_STEPS = {"CartPoleSwingUp": 1000, "CartPoleBalancing": 500}  # register_env.py:14-23
 
     def __init__(self, env, envs_per_rank, horizon, freq_rate=1, real_time_scale=0.02, precision="ref", rank=0,
-                 world=1, device=0, seed=0, init_noise=None):
+                 world=1, device=0, seed=0, init_noise=None, integrator="euler"):
         from .engine import Engine
 
         self.env, self.n, self.horizon, self.rank, self.world = env, int(envs_per_rank), int(horizon), rank, world
@@ -80,13 +80,14 @@ class ShardedRollout:
             init_noise = 0.1 if env == "HalfCheetahRunning" else 5e-3
         self.engine = Engine(env, self.n, freq_rate=freq_rate, real_time_scale=real_time_scale, precision=precision,
                              max_episode_steps=self.MAX_EPISODE_STEPS.get(env, 1000), device=device, seed=seed,
-                             env_index_offset=self.lo, init_noise=init_noise)
+                             env_index_offset=self.lo, init_noise=init_noise, integrator=integrator)
         self.device = self.engine.device
         self.obs_dim, self.act_dim = self.engine.obs_dim, self.engine.act_dim
         self.seed = seed
         self.actions = self.out = self.gathered = None
         self._events = []
-        self.kernel_name = "body_rollout_kernel" if (env == "HalfCheetahRunning" or "Double" in env) else "pend_rollout_staged_kernel"
+        self.kernel_name = ("body_rollout_kernel" if (env in ("HalfCheetahRunning", "HopperRunning") or "Double" in env or integrator != "euler")
+                            else "pend_rollout_staged_kernel")
 
     @property
     def action_bytes(self):
