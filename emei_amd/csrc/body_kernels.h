@@ -10,6 +10,7 @@
 // :197-249) and the device reset are generic and live here.
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
+//   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
 //
 // Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
 // observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
@@ -201,6 +202,8 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
     const bool obs_noise = a.noise.obs_on != 0;
     uint32_t done = 0;
+    R spare[Body::kSpareReset ? NS : 1];
+    bool have_spare = false;
 
     // this wave's action block of step t: wave_envs*NA contiguous floats starting at (t*n + i0)*NA
     float4 av[kActIt];
@@ -272,7 +275,23 @@ __global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Bod
             if (a.done_out) a.done_out[(int64_t)t * n + i] = (uint8_t)done;
         }
         if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
-            if (done != 0) {
+            if constexpr (Body::kSpareReset) {
+                // spare initial state per lane, re-drawn for every lane that lacks one when a resetting lane
+                // has none (see pendulum_kernels.h:maybe_reset): bodies whose episodes end at different times
+                if (__ballot((done != 0) & !have_spare) != 0ull) {
+                    if (!have_spare) {
+                        body_init<Body>(spare, a.seed, a.env_offset + (uint64_t)i, episode + 1u, a.noise);
+                        have_spare = true;
+                    }
+                }
+                if (done != 0) {
+                    ++episode;
+                    steps = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) s[k] = spare[k];
+                    have_spare = false;
+                }
+            } else if (done != 0) {  // episodes only end by TimeLimit, for all lanes at once
                 ++episode;
                 steps = 0;
                 body_init<Body>(s, a.seed, a.env_offset + (uint64_t)i, episode, a.noise);

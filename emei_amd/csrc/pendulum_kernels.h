@@ -204,14 +204,34 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
         bool trunc = (a.max_episode_steps > 0) & (steps >= a.max_episode_steps);
         done = (term ? EMEI_DONE_TERMINAL : 0u) | (trunc ? EMEI_DONE_TRUNCATED : 0u);
     };
+    // Early termination.  The reset of a lane needs a fresh initial state (Philox4x32-10 + the env's
+    // init distribution + its sin/cos): ~150-300 vector instructions that the whole wave executes for
+    // the one or two lanes that are done.  Each lane therefore keeps a SPARE initial state for its next
+    // episode: a reset just copies it, and spares are re-drawn only when a resetting lane has none —
+    // then for every lane without one at once (the first reset of a wave draws all 64).  The draw is a
+    // pure function of (seed, global env, episode), so results do not depend on when it is computed.
+    R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);
+    bool have_spare = false;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         // cold: laid out of line so that the usual case falls through
         if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
+            if (__ballot((done != 0) & !have_spare) != 0ull) {
+                if (!have_spare) {
+                    typename Env::Carry sc;
+                    sc.trig.tab = trig_s;
+                    Env::init(sp, a.seed, a.env_offset + (uint64_t)i, episode + 1u, a.p);
+                    Env::prime(sp, sc, a.p);
+                    sp_sn = sc.sn, sp_cs = sc.cs;
+                    have_spare = true;
+                }
+            }
             if (done != 0) {
                 ++episode;
                 steps = 0;
-                Env::init(s, a.seed, a.env_offset + (uint64_t)i, episode, a.p);
-                Env::prime(s, c, a.p);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = sp[k];
+                c.sn = sp_sn, c.cs = sp_cs;
+                have_spare = false;
             }
         }
     };
