@@ -158,6 +158,7 @@ static PendParams pend_params(int env_id, double dt, const float* init_sigma = n
     p.invw = p.M22 / (p.M11 * p.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
     p.tc = 0.02 < 2 * dt ? 2 * dt : 0.02;          // solref timeconst with MuJoCo's refsafe clamp
     p.dampratio = 1.0, p.dmin = 0.9, p.dmax = 0.95, p.width = 0.001;
+    p.limK = 1.0 / (p.dmax * p.dmax * p.tc * p.tc * p.dampratio * p.dampratio), p.limB = 2.0 / (p.dmax * p.tc);
     return p;
 }
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ R dotperp(V2<R> a, V2<R> b) { return fma_r(a.x, b.z, 
 
 template <typename R>
 __device__ __forceinline__ R impedance(R dist, R dmin, R dmax, R width) {
-    R x = fabs(dist) / width;
+    R x = div_r(fabs(dist), width);
     R y = x >= R(1) ? R(1) : (x <= R(0.5) ? R(2) * x * x : R(1) - R(2) * (R(1) - x) * (R(1) - x));
     R d = dmin + y * (dmax - dmin);
     return d < R(1e-4) ? R(1e-4) : (d > R(0.9999) ? R(0.9999) : d);
@@ -249,8 +249,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 if (in_pat(C, i)) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
             const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
-            const R Rr = (R(1) - imp) / imp * Aii;
-            const R force = (aref - acur) / (Aii + Rr);
+            const R Rr = div_r(R(1) - imp, imp) * Aii;
+            const R force = div_r(aref - acur, Aii + Rr);
             if (force > R(0)) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
@@ -308,10 +308,10 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                     an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
                 }
             const R imp = impedance(dist, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
-            const R k1 = (R(1) - imp) / imp;
-            const R fn = (-(R)m.cB * vn - (R)m.cK * imp * dist - an) / (Ann + k1 * Ann);
+            const R k1 = div_r(R(1) - imp, imp);
+            const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * dist - an, Ann + k1 * Ann);
             if (fn > R(0)) {
-                R ft = (-(R)m.cB * vt - at - Atn * fn) / (Att + k1 * Att);
+                R ft = div_r(-(R)m.cB * vt - at - Atn * fn, Att + k1 * Att);
                 const R lim = (R)m.friction * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll

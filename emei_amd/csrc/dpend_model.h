@@ -114,12 +114,12 @@ struct DPendBody {
             R wx, w1_, w2_;
             solve(R(1), R(0), R(0), wx, w1_, w2_);
             const R pos = dist - (R)m.margin;
-            const R xx = fabs(pos) / (R)m.width;
+            const R xx = div_r(fabs(pos), (R)m.width);
             const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);
             const R aref = -(R)m.B * (J * v[0]) - (R)m.K * imp * pos;
-            const R Rr = (R(1) - imp) / imp * (R)m.invw;
-            const R force = (aref - J * ax) / (wx + Rr);
+            const R Rr = div_r(R(1) - imp, imp) * (R)m.invw;
+            const R force = div_r(aref - J * ax, wx + Rr);
             if (force > R(0)) {
                 ax = fma_r(wx, J * force, ax);
                 a1_ = fma_r(w1_, J * force, a1_);

@@ -170,8 +170,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             for (int i = C; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
             const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
-            const R Rr = (R(1) - imp) / imp * Aii;
-            const R force = (aref - acur) / (Aii + Rr);
+            const R Rr = div_r(R(1) - imp, imp) * Aii;
+            const R force = div_r(aref - acur, Aii + Rr);
             if (force > R(0)) {
 #pragma unroll
                 for (int i = C; i < NV; ++i) z[i] = fma_r(yd[i], force, z[i]);
@@ -219,10 +219,10 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             }
             const R pos = dist - (R)m.margin;
             const R imp = impedance(pos, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
-            const R k1 = (R(1) - imp) / imp;
-            const R fn = (-(R)m.cB * vn - (R)m.cK * imp * pos - an) / (Ann + k1 * Ann);
+            const R k1 = div_r(R(1) - imp, imp);
+            const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - an, Ann + k1 * Ann);
             if (fn > R(0)) {
-                R ft = (-(R)m.cB * vt - at - Atn * fn) / (Att + k1 * Att);
+                R ft = div_r(-(R)m.cB * vt - at - Atn * fn, Att + k1 * Att);
                 const R lim = (R)m.friction[gi] * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll

@@ -81,12 +81,12 @@ struct InvPendBody {
         if (q[0] - (R)m.x_lo < R(0)) dist = q[0] - (R)m.x_lo, J = R(1);
         else if ((R)m.x_hi - q[0] < R(0)) dist = (R)m.x_hi - q[0], J = R(-1);
         if (J != R(0)) {
-            const R xx = fabs(dist) / (R)m.width;
+            const R xx = div_r(fabs(dist), (R)m.width);
             const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);
             const R aref = -(R)m.B * (J * v[0]) - (R)m.K * imp * dist;
-            const R Rr = (R(1) - imp) / imp * (R)m.invw;
-            const R force = (aref - J * a0) / (M22 * idet + Rr);
+            const R Rr = div_r(R(1) - imp, imp) * (R)m.invw;
+            const R force = div_r(aref - J * a0, M22 * idet + Rr);
             if (force > R(0)) {
                 a0 += (M22 * idet) * J * force;
                 a1 += (-M12 * idet) * J * force;

@@ -26,6 +26,7 @@ struct PendParams {
     double M11, M22, mpr, mgr, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
     double sin_off, cos_off, phi_off;  // phi = theta + phi_off is the com angle from +z
     double invw, tc, dampratio, dmin, dmax, width;
+    double limK, limB;  // 1 / (dmax^2 tc^2 dampratio^2), 2 / (dmax tc)
 };
 
 // =============================================================================================
@@ -208,16 +209,13 @@ struct InvPend {
             dist = (R)p.x_hi - x_old, J = R(-1);
         }
         if (J != R(0)) {
-            R tc = (R)p.tc;
-            R xx = fabs(dist) / (R)p.width;
+            R xx = div_r(fabs(dist), (R)p.width);
             R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             R imp = (R)p.dmin + y * ((R)p.dmax - (R)p.dmin);
-            R K = R(1) / ((R)p.dmax * (R)p.dmax * tc * tc * (R)p.dampratio * (R)p.dampratio);
-            R B = R(2) / ((R)p.dmax * tc);
-            R aref = -B * (J * v_old) - K * imp * dist;
+            R aref = -(R)p.limB * (J * v_old) - (R)p.limK * imp * dist;  // solref stiffness / damping, host constants
             R A = M22 * idet;
-            R Rr = (R(1) - imp) / imp * (R)p.invw;
-            R force = (aref - J * a0) / (A + Rr);
+            R Rr = div_r(R(1) - imp, imp) * (R)p.invw;
+            R force = div_r(aref - J * a0, A + Rr);
             if (force > R(0)) {
                 a0 += (M22 * idet) * J * force;
                 a1 += (-M12 * idet) * J * force;
