@@ -11,6 +11,7 @@
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
+//   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
 //
 // Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
 // observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
@@ -171,8 +172,12 @@ struct BodyArgs {
 };
 
 // emei_step / emei_rollout (mujoco_env.py:157-167) for every env of the shard
+// Body::kMinWavesPerEU = 2 caps the kernel at 256 registers so that two waves share a SIMD (measured per
+// body: it pays for the Hopper, whose RK4 working set then spills little; the cheetah spills 660 B/lane
+// to scratch at that cap and is faster with one resident wave and AGPRs as spill space)
 template <class Body, bool RK4>
-__global__ void __launch_bounds__(kBlock) body_rollout_kernel(const BodyArgs<Body> a) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEU)))
+    body_rollout_kernel(const BodyArgs<Body> a) {
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
     constexpr int kWaves = kBlock / kWave;

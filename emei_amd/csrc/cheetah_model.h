@@ -452,6 +452,7 @@ template <typename R>
 struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
+    static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;
     static Model make_model(double dt) { return cheetah::cheetah_make_model(dt); }

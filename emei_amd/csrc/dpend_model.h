@@ -65,6 +65,7 @@ template <int VARIANT, typename R>
 struct DPendBody {
     using real = R;
     using Model = dpend::Model;
+    static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;
     static Model make_model(double dt) { return dpend::make_model(VARIANT >= 2, dt); }
