@@ -72,6 +72,7 @@ class Engine:
                            {"iid": L.NOISE_IID, "shared": L.NOISE_SHARED}[noise_layout],
                            sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)))
         self._h = C.c_void_p()
+        self._host_io = None
         with torch.cuda.device(self.device):
             L.check(L.lib().emei_create(C.byref(cfg), C.byref(self._h)))
 
@@ -134,6 +135,30 @@ class Engine:
         L.check(L.lib().emei_step(self._h, _ptr(actions), dt, _ptr(obs), _ptr(rew), _ptr(done),
                                   L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
+
+    def step_host(self, action, auto_reset=False):
+        """The gym-style single-env call (`env.step(a)` of base_control.py:61-83 with host values in and out):
+        actions and results live in pinned host memory that the kernels address directly, so a step is
+        two launches (emei_step, emei_get_obs) and one stream synchronisation — no copy calls.
+        action: array-like [N(,act_dim)] -> (obs float64 [N,obs_dim] of the post-step state, obs float32
+        [N,obs_dim] as emitted by the step (pre auto-reset), reward float32 [N], done uint8 [N]) as NumPy
+        views of the pinned buffers (valid until the next call)."""
+        io = self._host_io
+        if io is None:
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            ashape = (self.n_envs,) if self.act_dim <= 1 else (self.n_envs, self.act_dim)
+            act = pin(ashape, torch.int64 if self.act_dim == 0 else torch.float32)
+            bufs = (act, pin((self.n_envs, self.obs_dim), torch.float64), pin((self.n_envs, self.obs_dim), torch.float32),
+                    pin((self.n_envs,), torch.float32), pin((self.n_envs,), torch.uint8))
+            io = self._host_io = bufs + tuple(b.numpy() for b in bufs)
+        act, obs64, obs32, rew, done, act_np, obs64_np, obs32_np, rew_np, done_np = io
+        act_np[...] = action
+        lib, st = L.lib(), _stream()
+        L.check(lib.emei_step(self._h, _ptr(act), _ACT_DTYPES[act.dtype], _ptr(obs32), _ptr(rew), _ptr(done),
+                              L.FLAG_AUTO_RESET if auto_reset else 0, st))
+        L.check(lib.emei_get_obs(self._h, _ptr(obs64), st))
+        torch.cuda.current_stream().synchronize()
+        return obs64_np, obs32_np, rew_np, done_np
 
     def rollout(self, actions, auto_reset=False, out=None):
         """actions [T,N(,act_dim)] -> obs [T,N,obs_dim] f32, reward [T,N] f32, done [T,N] u8; one launch."""

@@ -116,11 +116,11 @@ class HipEnv(EmeiEnv):
         eng = self.engine
         if self.num_envs == 1 and not isinstance(action, torch.Tensor):
             act = self._check_single_action(action)
-            a = torch.as_tensor(act, device=eng.device).reshape((1,) if eng.act_dim <= 1 else (1, eng.act_dim))
-            _, rew, done = eng.step(a.contiguous(), auto_reset=self.auto_reset)
-            d = int(done.item())
-            obs = self._obs_single() if not (self.auto_reset and d) else _.double()[0].cpu().numpy()
-            return obs, np.float64(rew.item()), np.bool_(d & 1), bool(d & 2), {}
+            obs64, obs32, rew, done = eng.step_host(act, auto_reset=self.auto_reset)
+            d = int(done[0])
+            # after an auto-reset the handle already holds the next episode's state: report the step's own obs
+            obs = obs64[0].copy() if not (self.auto_reset and d) else obs32[0].astype(np.float64)
+            return obs, np.float64(rew[0]), np.bool_(d & 1), bool(d & 2), {}
         a = action if isinstance(action, torch.Tensor) else torch.as_tensor(action)
         a = a.to(eng.device)
         if eng.act_dim == 0 and a.dtype not in (torch.uint8, torch.int32, torch.int64):
