@@ -84,6 +84,7 @@ SYMBOLS = {
     "emei_reward": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _dbl, _i32, _vp, _vp]),
     "emei_terminal": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp]),
     "emei_next_obs": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _vp, _vp]),
+    "emei_next_obs_ex": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -517,27 +517,56 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
     return fail(EMEI_ERR_INVALID, "emei_terminal: unknown env_id %d", env_id);
 }
 
-extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
-                             double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
-                             void* stream) {
+extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                                double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
+                                float* next_obs_out, void* stream) {
     if (n <= 0 || !obs || !actions || !next_obs_out) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad argument");
     if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad dt/freq_rate");
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype");
-    if (!is_pend(env_id))
-        return fail(EMEI_ERR_UNSUPPORTED, "emei_next_obs: not implemented for env_id %d", env_id);  // core.py:190-193
-    PendLaunch L;
-    L.op = PEND_OP_NEXT_OBS;
+    if (integrator < EMEI_INTEG_EULER || integrator > EMEI_INTEG_RK4)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_next_obs: integrator=%d", integrator);
+    int od, ad, sd;
+    if (emei_env_dims(env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
+    const bool ip_as_body = is_ip(env_id) && integrator != EMEI_INTEG_EULER;
+    if (is_pend(env_id) && !ip_as_body) {
+        PendLaunch L;
+        L.op = PEND_OP_NEXT_OBS;
+        L.env_id = env_id;
+        L.precision = precision;
+        L.obs_in = obs;
+        L.actions = actions;
+        L.action_dtype = action_dtype;
+        L.obs_out = next_obs_out;
+        L.n = n;
+        L.freq_rate = freq_rate;
+        L.p = pend_params(env_id, real_time_scale);
+        L.trig = current_device_trig();
+        L.stream = (hipStream_t)stream;
+        int rc = pend_launch(L);
+        return rc == EMEI_OK ? rc : fail(rc, "emei_next_obs: launch failed");
+    }
+    if (action_dtype != EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "continuous-action envs take float32 actions [n,%d]", ad);
+    BodyLaunch L;
+    L.op = BODY_OP_NEXT_OBS;
     L.env_id = env_id;
     L.precision = precision;
     L.obs_in = obs;
-    L.actions = actions;
-    L.action_dtype = action_dtype;
+    L.actions = (const float*)actions;
     L.obs_out = next_obs_out;
     L.n = n;
     L.freq_rate = freq_rate;
-    L.p = pend_params(env_id, real_time_scale);
-    L.trig = current_device_trig();
+    L.dt = real_time_scale;
+    L.integrator = integrator;
     L.stream = (hipStream_t)stream;
-    int rc = pend_launch(L);
+    int rc = body_launch(L);
+    if (rc == EMEI_ERR_UNSUPPORTED)
+        return fail(rc, "emei_next_obs: the observation of env_id %d does not determine its state", env_id);  // core.py:190-193
     return rc == EMEI_OK ? rc : fail(rc, "emei_next_obs: launch failed");
+}
+
+extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                             double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
+                             void* stream) {
+    return emei_next_obs_ex(env_id, n, obs, actions, action_dtype, real_time_scale, freq_rate, precision, EMEI_INTEG_EULER,
+                            next_obs_out, stream);
 }

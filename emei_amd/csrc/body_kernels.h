@@ -12,6 +12,7 @@
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
+//   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
 //
 // Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
 // observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
@@ -123,7 +124,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
     }
 }
 
-enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL };
+enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL, BODY_OP_NEXT_OBS };
 
 // host-side launch descriptor (abi.hip -> body_dispatch.hip -> body_tu.hip)
 struct BodyLaunch {
@@ -378,6 +379,30 @@ __global__ void __launch_bounds__(kBlock)
     terminal[i] = (uint8_t)Body::batch_terminal(obs + i * Body::NO, m);
 }
 
+// EmeiEnv.get_batch_next_obs (core.py:190-193; abstract in the reference): one env-step from caller-supplied
+// float32 observations, for bodies whose observation determines the state (Body::kObsIsState)
+template <class Body, bool RK4>
+__global__ void __launch_bounds__(kBlock)
+    body_next_obs_kernel(const float* obs, const float* actions, float* next_obs, int64_t n, int freq_rate, int semi,
+                         typename Body::Model m) {
+    using R = typename Body::real;
+    constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
+    static_assert(NS == NO, "observation and state must have the same layout");
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    R s[NS], pre[NS], ctrl[NA], rew;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[k] = pre[k] = (R)obs[i * NO + k];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) ctrl[k] = (R)actions[i * NA + k];
+    for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0);
+    float o[NO];
+    bool term;
+    Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term);
+#pragma unroll
+    for (int k = 0; k < NO; ++k) next_obs[i * NO + k] = o[k];
+}
+
 // every launch of one Body type (one translation unit instantiates exactly one Body: body_tu.hip)
 template <class Body>
 static int launch_body(const BodyLaunch& L) {
@@ -417,6 +442,18 @@ static int launch_body(const BodyLaunch& L) {
         case BODY_OP_TERMINAL:
             hipLaunchKernelGGL(body_terminal_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.done_out, L.n, m);
             break;
+        case BODY_OP_NEXT_OBS:
+            if constexpr (Body::kObsIsState) {
+                if (L.integrator == EMEI_INTEG_RK4)
+                    hipLaunchKernelGGL((body_next_obs_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
+                                       L.obs_out, L.n, L.freq_rate, 0, m);
+                else
+                    hipLaunchKernelGGL((body_next_obs_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
+                                       L.obs_out, L.n, L.freq_rate, (int)(L.integrator == EMEI_INTEG_SEMI_IMPLICIT), m);
+                break;
+            } else {
+                return EMEI_ERR_UNSUPPORTED;  // e.g. the double pendulum's observation "wrap" is not invertible
+            }
         default: return EMEI_ERR_INVALID;
     }
     return hipGetLastError() == hipSuccess ? EMEI_OK : EMEI_ERR_HIP;

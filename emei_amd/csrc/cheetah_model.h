@@ -3,7 +3,7 @@
 // Model: emei/envs/mujoco/assets/half_cheetah.xml stepped the way emei steps it
 // (emei/envs/mujoco/mujoco_env.py:86-109,169-195): MuJoCo's Euler substep (implicit joint damping)
 // with emei's forward-Euler position override.  Parity with libmujoco is UNPINNED (no MuJoCo in
-// the image): the CPU oracle (oracle/cheetah_oracle.c) restates the same model with MuJoCo's own
+// the image): the CPU oracle (oracle/planar_oracle.c) restates the same model with MuJoCo's own
 // algorithms (recursive Newton-Euler in joint coordinates, dense factorisation); this file is an
 // independent formulation of the same equations, chosen for the GPU:
 //
@@ -37,7 +37,7 @@ enum { P_BFOOT = 0, P_BSHIN = 1, P_BTHIGH = 2, P_FFOOT = 3, P_FSHIN = 4, P_FTHIG
 // structural non-zero of the (filled) lower triangle: same leg chain, or a row of torso/x/z
 __host__ __device__ constexpr bool nz(int i, int j) { return i >= 6 || (i / 3) == (j / 3); }
 
-// Model constants (computed on the host in double by cheetah.hip:make_model, passed by value).
+// Model constants (computed on the host in double by cheetah_make_model below, passed by value).
 struct Model {
     // mass-moment vector s_j (body frame) and constant diagonal inertia per link, permuted link order 0..6
     double sx[7], sz[7], diag[7];
@@ -453,6 +453,7 @@ struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;
     static Model make_model(double dt) { return cheetah::cheetah_make_model(dt); }

@@ -66,6 +66,7 @@ struct DPendBody {
     using real = R;
     using Model = dpend::Model;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;
     static Model make_model(double dt) { return dpend::make_model(VARIANT >= 2, dt); }

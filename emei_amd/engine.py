@@ -249,11 +249,11 @@ def batch_terminal(env_name, obs):
     return out.bool()
 
 
-def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref"):
+def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref", integrator="euler"):
     obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     actions = actions.to(obs.device).contiguous()
     out = torch.empty_like(obs)
-    L.check(L.lib().emei_next_obs(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(actions), _ACT_DTYPES[actions.dtype],
-                                  float(real_time_scale), int(freq_rate), {"ref": 0, "f32": 1}[precision], _ptr(out),
-                                  _stream()))
+    L.check(L.lib().emei_next_obs_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(actions), _ACT_DTYPES[actions.dtype],
+                                     float(real_time_scale), int(freq_rate), {"ref": 0, "f32": 1}[precision],
+                                     L.INTEGRATORS[integrator], _ptr(out), _stream()))
     return out

@@ -197,7 +197,8 @@ class HipEnv(EmeiEnv):
             a = a.reshape(-1).to(torch.int64)
         else:
             a = a.to(torch.float32).reshape(o.shape[0], -1)
-        nxt = E.batch_next_obs(self.ENGINE_NAME, o, a.contiguous(), self.real_time_scale, self.freq_rate, self.precision)
+        nxt = E.batch_next_obs(self.ENGINE_NAME, o, a.contiguous(), self.real_time_scale, self.freq_rate, self.precision,
+                               self.ENGINE_INTEGRATOR or "euler")
         if isinstance(obs, torch.Tensor):
             return nxt
         return nxt.cpu().numpy().astype(np.float64)

@@ -193,6 +193,14 @@ EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* 
                   double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
                   void* stream);
 
+/* The same for every env whose observation determines its state (CartPole, InvertedPendulum, HalfCheetah,
+ * Hopper; the InvertedDoublePendulum's observation "wrap", inverted_double_pendulum.py:59, is not
+ * invertible -> EMEI_ERR_UNSUPPORTED), with the integrator of mujoco_env.py:70-79 (classic control
+ * ignores it).  No observation noise is added. */
+EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                     double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
+                     float* next_obs_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,43 @@ def test_abi_v1_config_still_accepted():
     torch.cuda.synchronize()
     assert float(out.std()) == pytest.approx(0.1, rel=0.05)
     L.lib().emei_destroy(h)
+
+
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+@pytest.mark.parametrize("body", ["ip", "cheetah", "hopper"])
+def test_batch_next_obs_equals_a_step_from_that_state(body, integrator):
+    """get_batch_next_obs (core.py:190-193, abstract in the reference): one env-step from caller-supplied
+    float32 observations == set_state(those rows) + step, for every body whose observation determines the state."""
+    from emei_amd import engine as E
+
+    rng = np.random.default_rng(17)
+    n = 333
+    name, s0, act, _, dt = _case(body, rng, n)
+    if body == "ip":
+        s0[:, 1] = (s0[:, 1] + np.pi) % (2 * np.pi) - np.pi  # observations carry the wrapped angle
+    obs32 = torch.as_tensor(s0.astype(np.float32), device="cuda")
+    act32 = torch.as_tensor(act.astype(np.float32), device="cuda")
+    nxt = E.batch_next_obs(name, obs32, act32 if body != "ip" else act32.reshape(-1), dt, 2, "ref", integrator)
+    eng = _engine(name, n, freq_rate=2, real_time_scale=dt, integrator=integrator)
+    eng.set_state(obs32.double().cpu().numpy())
+    obs, _, _ = eng.step(act32)
+    assert rel_err(nxt.cpu().numpy(), obs.cpu().numpy()) <= 1e-6, (body, integrator)
+
+
+def test_batch_next_obs_env_surface_and_unsupported():
+    import emei_amd
+    from emei_amd import engine as E
+
+    env = emei_amd.HopperRunningEnv()
+    o = np.tile([0, 1.25, 0, -0.1, -0.2, 0.05, 0, 0, 0, 0, 0, 0.0], (8, 1))
+    a = np.zeros((8, 3))
+    with pytest.raises(AssertionError):  # `assert self.frozen`, core.py:191
+        env.get_batch_next_obs(o, action=a)
+    np.random.seed(0)
+    env.reset()
+    env.freeze()
+    nxt = env.get_batch_next_obs(o, action=a)
+    env.unfreeze()
+    assert nxt.shape == (8, 12) and nxt.dtype == np.float64 and np.all(nxt[:, 1] < 1.25) and np.allclose(nxt, nxt[:1])
+    with pytest.raises(NotImplementedError):  # the double pendulum's observation wrap is not invertible
+        E.batch_next_obs("BoundaryInvertedDoublePendulumSwingUp", torch.zeros((4, 6), device="cuda"), torch.zeros((4, 1), device="cuda"))

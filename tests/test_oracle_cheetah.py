@@ -1,5 +1,5 @@
 """The HalfCheetah-style oracle: first-party pieces against the golden vectors, and internal consistency
-of the restated dynamics (parity with libmujoco is unpinned, see oracle/cheetah_oracle.c)."""
+of the restated dynamics (parity with libmujoco is unpinned, see oracle/planar_oracle.c)."""
 import numpy as np
 
 from conftest import rel_err
