@@ -75,6 +75,133 @@ __device__ __forceinline__ R impedance(R dist, R dmin, R dmax, R width) {
     return d < R(1e-4) ? R(1e-4) : (d > R(0.9999) ? R(0.9999) : d);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Model constants from assets/half_cheetah.xml (inertiafromgeom, settotalmass = 14, xml:35), evaluated at
+// COMPILE time: the kernels read them from the constexpr object kGeom below, so they are immediates
+// (s_mov) instead of ~220 scalar registers of kernel arguments that would not fit the SGPR file and came
+// back through v_readlane spills (28 % of the executed vector instructions).  Only what depends on the
+// run-time dt (solref stiffness / damping, dt itself) travels as a kernel argument.
+namespace cheetah_host {
+struct H2 {
+    double x, z;
+};
+// sin / cos for compile-time evaluation (|a| of a few radians; Taylor after reduction to [-pi/4, pi/4], ~1e-16)
+constexpr void ce_sincos(double a, double& sn, double& cs) {
+    const double pio2_hi = 1.5707963267948966, pio2_lo = 6.123233995736766e-17;
+    const double kq = a / pio2_hi;
+    const long k = (long)(kq + (kq >= 0 ? 0.5 : -0.5));
+    const double r = (a - k * pio2_hi) - k * pio2_lo, z = r * r;
+    double ts = 0, tc = 0;
+    for (int n = 10; n >= 0; --n) {  // sum_{n} (-1)^n z^n / (2n+1)!  and  / (2n)!
+        double fs = 1, fc = 1;
+        for (int q = 1; q <= 2 * n + 1; ++q) fs *= q;
+        for (int q = 1; q <= 2 * n; ++q) fc *= q;
+        ts = ts * z + ((n & 1) ? -1.0 : 1.0) / fs;
+        tc = tc * z + ((n & 1) ? -1.0 : 1.0) / fc;
+    }
+    // Horner above folds z^n in ascending order of n from the highest term down: ts = sum c_n z^n
+    const double s0 = r * ts, c0 = tc;
+    switch (((k % 4) + 4) % 4) {
+        case 0: sn = s0, cs = c0; break;
+        case 1: sn = c0, cs = -s0; break;
+        case 2: sn = -s0, cs = -c0; break;
+        default: sn = -c0, cs = s0; break;
+    }
+}
+constexpr H2 hrot(double a, H2 v) {
+    double sn = 0, cs = 0;
+    ce_sincos(a, sn, cs);
+    return {v.x * cs + v.z * sn, -v.x * sn + v.z * cs};
+}
+constexpr double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
+constexpr double capsule_inertia_perp(double rho, double r, double half) {
+    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
+    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+}
+}  // namespace cheetah_host
+
+constexpr Model cheetah_make_model(double dt) {
+    using namespace cheetah_host;
+    Model m{};
+    const double r = 0.046, rho = 1000.0;
+    // bodies in the xml's order: torso, bthigh, bshin, bfoot, fthigh, fshin, ffoot
+    const int parent[7] = {-1, 0, 1, 2, 0, 4, 5};
+    const H2 bpos[7] = {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}};
+    struct G {
+        int body;
+        H2 c;
+        double ang, half;
+    };
+    const G g[8] = {{0, {0, 0}, M_PI / 2, 0.5},       {0, {0.6, 0.1}, 0.87, 0.15},       {1, {0.1, -0.13}, -3.8, 0.145},
+              {2, {-0.14, -0.07}, -2.03, 0.15}, {3, {0.03, -0.097}, -0.27, 0.094}, {4, {-0.07, -0.12}, 0.52, 0.133},
+              {5, {0.065, -0.09}, -0.6, 0.106}, {6, {0.045, -0.07}, -0.6, 0.07}};
+    double gm[8] = {}, gi[8] = {}, total = 0;
+    for (int k = 0; k < 8; ++k) gm[k] = capsule_mass(rho, r, g[k].half), gi[k] = capsule_inertia_perp(rho, r, g[k].half), total += gm[k];
+    double mass[7] = {}, inertia[7] = {};
+    H2 com[7] = {};
+    for (int b = 0; b < 7; ++b) {
+        double mb = 0;
+        H2 c = {0, 0};
+        for (int k = 0; k < 8; ++k)
+            if (g[k].body == b) mb += gm[k], c.x += gm[k] * g[k].c.x, c.z += gm[k] * g[k].c.z;
+        c.x /= mb, c.z /= mb;
+        double I = 0;
+        for (int k = 0; k < 8; ++k)
+            if (g[k].body == b) {
+                double dx = g[k].c.x - c.x, dz = g[k].c.z - c.z;
+                I += gi[k] + gm[k] * (dx * dx + dz * dz);
+            }
+        mass[b] = mb, com[b] = c, inertia[b] = I;
+    }
+    const double s = 14.0 / total;
+    for (int b = 0; b < 7; ++b) mass[b] *= s, inertia[b] *= s;
+    // subtree masses
+    double sub[7] = {};
+    for (int b = 0; b < 7; ++b) sub[b] = mass[b];
+    for (int b = 6; b > 0; --b) sub[parent[b]] += sub[b];
+    // permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso  <- xml body index
+    const int perm_body[7] = {3, 2, 1, 6, 5, 4, 0};
+    for (int p = 0; p < 7; ++p) {
+        const int b = perm_body[p];
+        double sx = mass[b] * com[b].x, sz = mass[b] * com[b].z;
+        double dg = inertia[b] + mass[b] * (com[b].x * com[b].x + com[b].z * com[b].z);
+        for (int c = 1; c < 7; ++c)
+            if (parent[c] == b) {
+                sx += sub[c] * bpos[c].x, sz += sub[c] * bpos[c].z;
+                dg += sub[c] * (bpos[c].x * bpos[c].x + bpos[c].z * bpos[c].z);
+            }
+        m.sx[p] = sx, m.sz[p] = sz, m.diag[p] = dg;
+    }
+    m.d_tb[0] = bpos[1].x, m.d_tb[1] = bpos[1].z;
+    m.d_tf[0] = bpos[4].x, m.d_tf[1] = bpos[4].z;
+    m.d_bt_bs[0] = bpos[2].x, m.d_bt_bs[1] = bpos[2].z;
+    m.d_bs_bf[0] = bpos[3].x, m.d_bs_bf[1] = bpos[3].z;
+    m.d_ft_fs[0] = bpos[5].x, m.d_ft_fs[1] = bpos[5].z;
+    m.d_fs_ff[0] = bpos[6].x, m.d_fs_ff[1] = bpos[6].z;
+    m.mtot = 14.0, m.gravity = 9.81, m.z0 = bpos[0].z;
+    const double stiff[6] = {240, 180, 120, 180, 120, 60}, damp[6] = {6, 4.5, 3, 4.5, 3, 1.5};
+    const double lo[6] = {-0.52, -0.785, -0.4, -1.0, -1.2, -0.5}, hi[6] = {1.05, 0.785, 0.785, 0.7, 0.87, 0.5};
+    const double gear[6] = {120, 90, 60, 120, 60, 30};
+    for (int k = 0; k < 6; ++k)
+        m.stiff[k] = stiff[k], m.damp[k] = damp[k], m.arm[k] = 0.1, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = gear[k];
+    for (int k = 0; k < 8; ++k) {  // capsule end spheres: centre -/+ half * axis, axis = +z rotated by ang about y
+        H2 ax = hrot(g[k].ang, {0, 1});
+        m.geom_end[2 * k][0] = g[k].c.x - g[k].half * ax.x, m.geom_end[2 * k][1] = g[k].c.z - g[k].half * ax.z;
+        m.geom_end[2 * k + 1][0] = g[k].c.x + g[k].half * ax.x, m.geom_end[2 * k + 1][1] = g[k].c.z + g[k].half * ax.z;
+    }
+    m.radius = r, m.friction = 0.4;
+    // solref (.02, 1) with MuJoCo's refsafe clamp timeconst >= 2 dt; solimp contacts (0,.8,.01), limits (0,.8,.03)
+    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.8;
+    m.cK = m.lK = 1.0 / (dmax * dmax * tc * tc), m.cB = m.lB = 2.0 / (dmax * tc);
+    m.c_dmin = 0.0, m.c_dmax = dmax, m.c_width = 0.01;
+    m.l_dmin = 0.0, m.l_dmax = dmax, m.l_width = 0.03;
+    m.dt = dt;
+    return m;
+}
+
+// every dt-independent constant of the model, as compile-time immediates for the device code
+__device__ constexpr Model kGeom = cheetah_make_model(0.002);
+
 // Sparse LDL^T in the permuted order.  L is stored in the strict lower triangle of A, 1/D in invd.
 template <typename R>
 __device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
@@ -140,14 +267,14 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     for (int b = 0; b < 7; ++b) sincos_r(phi[b], sn[b], cs[b]);
     V2<R> S[7];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) S[b] = rot(cs[b], sn[b], (R)m.sx[b], (R)m.sz[b]);
+    for (int b = 0; b < 7; ++b) S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
     // rotated link vectors
-    const V2<R> Dtb = rot(cs[6], sn[6], (R)m.d_tb[0], (R)m.d_tb[1]);          // torso -> bthigh joint
-    const V2<R> Dtf = rot(cs[6], sn[6], (R)m.d_tf[0], (R)m.d_tf[1]);          // torso -> fthigh joint
-    const V2<R> Dbt = rot(cs[2], sn[2], (R)m.d_bt_bs[0], (R)m.d_bt_bs[1]);    // bthigh -> bshin joint
-    const V2<R> Dbs = rot(cs[1], sn[1], (R)m.d_bs_bf[0], (R)m.d_bs_bf[1]);    // bshin -> bfoot joint
-    const V2<R> Dft = rot(cs[5], sn[5], (R)m.d_ft_fs[0], (R)m.d_ft_fs[1]);    // fthigh -> fshin joint
-    const V2<R> Dfs = rot(cs[4], sn[4], (R)m.d_fs_ff[0], (R)m.d_fs_ff[1]);    // fshin -> ffoot joint
+    const V2<R> Dtb = rot(cs[6], sn[6], (R)kGeom.d_tb[0], (R)kGeom.d_tb[1]);          // torso -> bthigh joint
+    const V2<R> Dtf = rot(cs[6], sn[6], (R)kGeom.d_tf[0], (R)kGeom.d_tf[1]);          // torso -> fthigh joint
+    const V2<R> Dbt = rot(cs[2], sn[2], (R)kGeom.d_bt_bs[0], (R)kGeom.d_bt_bs[1]);    // bthigh -> bshin joint
+    const V2<R> Dbs = rot(cs[1], sn[1], (R)kGeom.d_bs_bf[0], (R)kGeom.d_bs_bf[1]);    // bshin -> bfoot joint
+    const V2<R> Dft = rot(cs[5], sn[5], (R)kGeom.d_ft_fs[0], (R)kGeom.d_ft_fs[1]);    // fthigh -> fshin joint
+    const V2<R> Dfs = rot(cs[4], sn[4], (R)kGeom.d_fs_ff[0], (R)kGeom.d_fs_ff[1]);    // fshin -> ffoot joint
 
     // ---- inertia matrix (lower triangle, permuted) and generalized forces in absolute coordinates
     R A[NV][NV];
@@ -156,8 +283,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
         for (int j = 0; j < NV; ++j) A[i][j] = R(0);
 #pragma unroll
-    for (int b = 0; b < 7; ++b) A[b][b] = (R)m.diag[b];
-    A[P_X][P_X] = (R)m.mtot, A[P_Z][P_Z] = (R)m.mtot;
+    for (int b = 0; b < 7; ++b) A[b][b] = (R)kGeom.diag[b];
+    A[P_X][P_X] = (R)kGeom.mtot, A[P_Z][P_Z] = (R)kGeom.mtot;
     // angle-angle couplings along each chain: (ancestor link vector towards the descendant) . S_descendant
     A[P_BSHIN][P_BFOOT] = dot(Dbs, S[0]);
     A[P_BTHIGH][P_BFOOT] = dot(Dbt, S[0]);
@@ -186,11 +313,11 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
         for (int b = 0; b < 7; ++b) fx = fma_r(w2[b], S[b].x, fx), fz = fma_r(w2[b], S[b].z, fz);
         f[P_X] = fx;
-        f[P_Z] = fz - (R)m.mtot * (R)m.gravity;
+        f[P_Z] = fz - (R)kGeom.mtot * (R)kGeom.gravity;
     }
     // Q_phi_i = g S_i.x + sum_{j != i, same chain} Omega_j^2 * (l_bj . perp(l_bi) summed over bodies)
     //   i ancestor of j:  S_j . perp(D_i->j);   j ancestor of i:  D_j->i . perp(S_i)
-    const R g = (R)m.gravity;
+    const R g = (R)kGeom.gravity;
     f[P_BFOOT] = fma_r(g, S[0].x, w2[1] * dotperp(Dbs, S[0]) + w2[2] * dotperp(Dbt, S[0]) + w2[6] * dotperp(Dtb, S[0]));
     f[P_BSHIN] = fma_r(g, S[1].x, w2[0] * dotperp(S[0], Dbs) + w2[2] * dotperp(Dbt, S[1]) + w2[6] * dotperp(Dtb, S[1]));
     f[P_BTHIGH] = fma_r(g, S[2].x, w2[0] * dotperp(S[0], Dbt) + w2[1] * dotperp(S[1], Dbt) + w2[6] * dotperp(Dtb, S[2]));
@@ -207,10 +334,10 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);   // ctrlrange +-1
-        const R tau = (R)m.gear[k] * c - (R)m.stiff[k] * q[3 + k] - (R)m.damp[k] * v[3 + k];
+        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.stiff[k] * q[3 + k] - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] += tau;
         f[jp[k]] -= tau;
-        const R e = (R)m.arm[k] + hd * (R)m.damp[k];  // armature + implicit damping: M + h D on theta_k
+        const R e = (R)kGeom.arm[k] + hd * (R)kGeom.damp[k];  // armature + implicit damping: M + h D on theta_k
         A[jc[k]][jc[k]] += e;
         A[jp[k]][jp[k]] += e;
         // the (child,parent) entry lives in the lower triangle at [max][min]
@@ -235,8 +362,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
         constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];  // child index < parent index
         const R th = q[3 + k];
         R dist = R(0), J = R(0);
-        if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
-        else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
+        if (th - (R)kGeom.lo[k] < R(0)) dist = th - (R)kGeom.lo[k], J = R(1);
+        else if ((R)kGeom.hi[k] - th < R(0)) dist = (R)kGeom.hi[k] - th, J = R(-1);
         if (J != R(0)) {
             R y[NV], yd[NV];
 #pragma unroll
@@ -247,7 +374,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
             for (int i = 0; i < NV; ++i)
                 if (in_pat(C, i)) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
-            const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
+            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = div_r(R(1) - imp, imp) * Aii;
             const R force = div_r(aref - acur, Aii + Rr);
@@ -261,7 +388,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
     limit(std::integral_constant<int, 3>{}), limit(std::integral_constant<int, 4>{}), limit(std::integral_constant<int, 5>{});
     // body origins (world) for the contact points
-    const V2<R> o_t = {q[0], (R)m.z0 + q[1]};
+    const V2<R> o_t = {q[0], (R)kGeom.z0 + q[1]};
     const V2<R> o_bt = {o_t.x + Dtb.x, o_t.z + Dtb.z}, o_bs = {o_bt.x + Dbt.x, o_bt.z + Dbt.z},
                 o_bf = {o_bs.x + Dbs.x, o_bs.z + Dbs.z};
     const V2<R> o_ft = {o_t.x + Dtf.x, o_t.z + Dtf.z}, o_fs = {o_ft.x + Dft.x, o_ft.z + Dft.z},
@@ -277,9 +404,9 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     auto contact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
                        __attribute__((always_inline)) {
         constexpr int LNK = decltype(lnk_c)::value;
-        const V2<R> e = rot(cs[LNK], sn[LNK], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
+        const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
         const R sz_ = org.z + e.z;
-        const R dist = sz_ - (R)m.radius;
+        const R dist = sz_ - (R)kGeom.radius;
         if (dist < R(0)) {
             // contact point midway between the surfaces: p = (s.x, dist/2); offset from the body origin
             const V2<R> r = {e.x, R(0.5) * dist - org.z};
@@ -307,12 +434,12 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                     Ann = fma_r(Jz[i], dz[i], Ann), Att = fma_r(Jx[i], dx[i], Att), Atn = fma_r(Jx[i], dz[i], Atn);
                     an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
                 }
-            const R imp = impedance(dist, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
+            const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
             const R k1 = div_r(R(1) - imp, imp);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * dist - an, Ann + k1 * Ann);
             if (fn > R(0)) {
                 R ft = div_r(-(R)m.cB * vt - at - Atn * fn, Att + k1 * Att);
-                const R lim = (R)m.friction * fn;
+                const R lim = (R)kGeom.friction * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
@@ -349,99 +476,6 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[P_TORSO];
     qacc[3] = acc[P_BTHIGH] - acc[P_TORSO], qacc[4] = acc[P_BSHIN] - acc[P_BTHIGH], qacc[5] = acc[P_BFOOT] - acc[P_BSHIN];
     qacc[6] = acc[P_FTHIGH] - acc[P_TORSO], qacc[7] = acc[P_FSHIN] - acc[P_FTHIGH], qacc[8] = acc[P_FFOOT] - acc[P_FSHIN];
-}
-
-// ---------------------------------------------------------------------------------------------
-// host: model constants from assets/half_cheetah.xml (inertiafromgeom, settotalmass = 14, xml:35)
-namespace cheetah_host {
-struct H2 {
-    double x, z;
-};
-inline H2 hrot(double a, H2 v) { return {v.x * std::cos(a) + v.z * std::sin(a), -v.x * std::sin(a) + v.z * std::cos(a)}; }
-inline double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
-inline double capsule_inertia_perp(double rho, double r, double half) {
-    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
-    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
-}
-}  // namespace cheetah_host
-
-inline Model cheetah_make_model(double dt) {
-    using namespace cheetah_host;
-    Model m;
-    memset(&m, 0, sizeof(m));
-    const double r = 0.046, rho = 1000.0;
-    // bodies in the xml's order: torso, bthigh, bshin, bfoot, fthigh, fshin, ffoot
-    const int parent[7] = {-1, 0, 1, 2, 0, 4, 5};
-    const H2 bpos[7] = {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}};
-    struct G {
-        int body;
-        H2 c;
-        double ang, half;
-    } g[8] = {{0, {0, 0}, M_PI / 2, 0.5},       {0, {0.6, 0.1}, 0.87, 0.15},       {1, {0.1, -0.13}, -3.8, 0.145},
-              {2, {-0.14, -0.07}, -2.03, 0.15}, {3, {0.03, -0.097}, -0.27, 0.094}, {4, {-0.07, -0.12}, 0.52, 0.133},
-              {5, {0.065, -0.09}, -0.6, 0.106}, {6, {0.045, -0.07}, -0.6, 0.07}};
-    double gm[8], gi[8], total = 0;
-    for (int k = 0; k < 8; ++k) gm[k] = capsule_mass(rho, r, g[k].half), gi[k] = capsule_inertia_perp(rho, r, g[k].half), total += gm[k];
-    double mass[7], inertia[7];
-    H2 com[7];
-    for (int b = 0; b < 7; ++b) {
-        double mb = 0;
-        H2 c = {0, 0};
-        for (int k = 0; k < 8; ++k)
-            if (g[k].body == b) mb += gm[k], c.x += gm[k] * g[k].c.x, c.z += gm[k] * g[k].c.z;
-        c.x /= mb, c.z /= mb;
-        double I = 0;
-        for (int k = 0; k < 8; ++k)
-            if (g[k].body == b) {
-                double dx = g[k].c.x - c.x, dz = g[k].c.z - c.z;
-                I += gi[k] + gm[k] * (dx * dx + dz * dz);
-            }
-        mass[b] = mb, com[b] = c, inertia[b] = I;
-    }
-    const double s = 14.0 / total;
-    for (int b = 0; b < 7; ++b) mass[b] *= s, inertia[b] *= s;
-    // subtree masses
-    double sub[7];
-    for (int b = 0; b < 7; ++b) sub[b] = mass[b];
-    for (int b = 6; b > 0; --b) sub[parent[b]] += sub[b];
-    // permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso  <- xml body index
-    const int perm_body[7] = {3, 2, 1, 6, 5, 4, 0};
-    for (int p = 0; p < 7; ++p) {
-        const int b = perm_body[p];
-        double sx = mass[b] * com[b].x, sz = mass[b] * com[b].z;
-        double dg = inertia[b] + mass[b] * (com[b].x * com[b].x + com[b].z * com[b].z);
-        for (int c = 1; c < 7; ++c)
-            if (parent[c] == b) {
-                sx += sub[c] * bpos[c].x, sz += sub[c] * bpos[c].z;
-                dg += sub[c] * (bpos[c].x * bpos[c].x + bpos[c].z * bpos[c].z);
-            }
-        m.sx[p] = sx, m.sz[p] = sz, m.diag[p] = dg;
-    }
-    m.d_tb[0] = bpos[1].x, m.d_tb[1] = bpos[1].z;
-    m.d_tf[0] = bpos[4].x, m.d_tf[1] = bpos[4].z;
-    m.d_bt_bs[0] = bpos[2].x, m.d_bt_bs[1] = bpos[2].z;
-    m.d_bs_bf[0] = bpos[3].x, m.d_bs_bf[1] = bpos[3].z;
-    m.d_ft_fs[0] = bpos[5].x, m.d_ft_fs[1] = bpos[5].z;
-    m.d_fs_ff[0] = bpos[6].x, m.d_fs_ff[1] = bpos[6].z;
-    m.mtot = 14.0, m.gravity = 9.81, m.z0 = bpos[0].z;
-    const double stiff[6] = {240, 180, 120, 180, 120, 60}, damp[6] = {6, 4.5, 3, 4.5, 3, 1.5};
-    const double lo[6] = {-0.52, -0.785, -0.4, -1.0, -1.2, -0.5}, hi[6] = {1.05, 0.785, 0.785, 0.7, 0.87, 0.5};
-    const double gear[6] = {120, 90, 60, 120, 60, 30};
-    for (int k = 0; k < 6; ++k)
-        m.stiff[k] = stiff[k], m.damp[k] = damp[k], m.arm[k] = 0.1, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = gear[k];
-    for (int k = 0; k < 8; ++k) {  // capsule end spheres: centre -/+ half * axis, axis = +z rotated by ang about y
-        H2 ax = hrot(g[k].ang, {0, 1});
-        m.geom_end[2 * k][0] = g[k].c.x - g[k].half * ax.x, m.geom_end[2 * k][1] = g[k].c.z - g[k].half * ax.z;
-        m.geom_end[2 * k + 1][0] = g[k].c.x + g[k].half * ax.x, m.geom_end[2 * k + 1][1] = g[k].c.z + g[k].half * ax.z;
-    }
-    m.radius = r, m.friction = 0.4;
-    // solref (.02, 1) with MuJoCo's refsafe clamp timeconst >= 2 dt; solimp contacts (0,.8,.01), limits (0,.8,.03)
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.8;
-    m.cK = m.lK = 1.0 / (dmax * dmax * tc * tc), m.cB = m.lB = 2.0 / (dmax * tc);
-    m.c_dmin = 0.0, m.c_dmax = dmax, m.c_width = 0.01;
-    m.l_dmin = 0.0, m.l_dmax = dmax, m.l_width = 0.03;
-    m.dt = dt;
-    return m;
 }
 
 }  // namespace cheetah

@@ -49,6 +49,56 @@ using cheetah::impedance;
 using cheetah::rot;
 using cheetah::V2;
 
+// model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000),
+// evaluated at compile time like the cheetah's (cheetah_model.h:kGeom)
+constexpr Model make_model(double dt) {
+    using namespace cheetah::cheetah_host;
+    Model m{};
+    const double rho = 1000.0, deg = M_PI / 180.0;
+    // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
+    // foot (0,.1) xml:29, leg (0,.6) :25, thigh (0,1.05) :21, torso (0,1.25) :17
+    const double half[NL] = {0.195, 0.25, 0.225, 0.2}, rad[NL] = {0.06, 0.04, 0.05, 0.05};  // capsules :30,26,22,18
+    const H2 gc[NL] = {{0.065, 0}, {0, -0.25}, {0, -0.225}, {0, 0}};     // capsule centres, link frame
+    const double gang[NL] = {M_PI / 2, 0, 0, 0};                          // foot capsule lies along x
+    const H2 dvec[NL] = {{0, 0}, {0, -0.5}, {0, -0.45}, {0, -0.2}};       // to the child joint
+    double mass[NL] = {}, inertia[NL] = {}, sub[NL] = {};
+    for (int b = 0; b < NL; ++b) {
+        mass[b] = capsule_mass(rho, rad[b], half[b]);
+        inertia[b] = capsule_inertia_perp(rho, rad[b], half[b]);
+        sub[b] = mass[b] + (b ? sub[b - 1] : 0.0);  // link b carries links 0..b-1
+    }
+    for (int b = 0; b < NL; ++b) {
+        const double carried = b ? sub[b - 1] : 0.0;
+        m.sx[b] = mass[b] * gc[b].x + carried * dvec[b].x, m.sz[b] = mass[b] * gc[b].z + carried * dvec[b].z;
+        m.diag[b] = inertia[b] + mass[b] * (gc[b].x * gc[b].x + gc[b].z * gc[b].z) +
+                    carried * (dvec[b].x * dvec[b].x + dvec[b].z * dvec[b].z);
+        m.d[b][0] = dvec[b].x, m.d[b][1] = dvec[b].z;
+    }
+    m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = 1.25 - 1.25;  // body pos z 1.25, rootz ref 1.25 (:16)
+    const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};  // :21,25,29
+    for (int k = 0; k < 3; ++k) m.damp[k] = 1.0, m.arm[k] = 1.0, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = 200.0;  // :5,37-39
+    const int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
+    for (int g = 0; g < 4; ++g) {
+        const int b = geom_link[g];
+        const H2 ax = hrot(gang[b], {0, 1});
+        m.geom_end[2 * g][0] = gc[b].x - half[b] * ax.x, m.geom_end[2 * g][1] = gc[b].z - half[b] * ax.z;
+        m.geom_end[2 * g + 1][0] = gc[b].x + half[b] * ax.x, m.geom_end[2 * g + 1][1] = gc[b].z + half[b] * ax.z;
+        m.radius[g] = rad[b];
+        m.friction[g] = g == 3 ? 2.0 : 1.0;  // max(floor 1.0, geom .9 | 2.0) (:18,22,26,30)
+    }
+    m.margin = 0.001;  // :6
+    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02;  // solref (.02 1), refsafe
+    m.c_dmin = 0.8, m.c_dmax = 0.8, m.c_width = 0.01;  // geom solimp (.8 .8 .01) :6
+    m.l_dmin = 0.9, m.l_dmax = 0.95, m.l_width = 0.001;  // MuJoCo's joint-limit defaults
+    m.cK = 1.0 / (m.c_dmax * m.c_dmax * tc * tc), m.cB = 2.0 / (m.c_dmax * tc);
+    m.lK = 1.0 / (m.l_dmax * m.l_dmax * tc * tc), m.lB = 2.0 / (m.l_dmax * tc);
+    m.dt = dt;
+    return m;
+}
+
+// every dt-independent constant of the model, as compile-time immediates for the device code
+__device__ constexpr Model kGeom = make_model(0.002);
+
 // dense LDL^T of the symmetric 6x6 (lower triangle of A); L in the strict lower triangle, 1/D in invd
 template <typename R>
 __device__ __forceinline__ void ldl_factor(R (&A)[NV][NV], R (&invd)[NV]) {
@@ -98,8 +148,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
     for (int b = 0; b < NL; ++b) {
         sincos_r(phi[b], sn[b], cs[b]);
-        S[b] = rot(cs[b], sn[b], (R)m.sx[b], (R)m.sz[b]);
-        D[b] = rot(cs[b], sn[b], (R)m.d[b][0], (R)m.d[b][1]);
+        S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
+        D[b] = rot(cs[b], sn[b], (R)kGeom.d[b][0], (R)kGeom.d[b][1]);
         w2[b] = om[b] * om[b];
     }
     // ---- inertia (lower triangle) and right-hand side in absolute coordinates
@@ -108,11 +158,11 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int j = 0; j < NV; ++j) A[i][j] = R(0);
-    const R g = (R)m.gravity;
+    const R g = (R)kGeom.gravity;
     R fx = R(0), fz = R(0);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        A[i][i] = (R)m.diag[i];
+        A[i][i] = (R)kGeom.diag[i];
         A[P_X][i] = S[i].z, A[P_Z][i] = -S[i].x;  // perp(S_i)
         R fi = g * S[i].x;
 #pragma unroll
@@ -127,17 +177,17 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
         f[i] = fi;
         fx = fma_r(w2[i], S[i].x, fx), fz = fma_r(w2[i], S[i].z, fz);
     }
-    A[P_X][P_X] = (R)m.mtot, A[P_Z][P_Z] = (R)m.mtot;
-    f[P_X] = fx, f[P_Z] = fz - (R)m.mtot * g;
+    A[P_X][P_X] = (R)kGeom.mtot, A[P_Z][P_Z] = (R)kGeom.mtot;
+    f[P_X] = fx, f[P_Z] = fz - (R)kGeom.mtot * g;
     // ---- joints thigh, leg, foot: child link / parent link; theta_k = -(phi_c - phi_p)
     constexpr int jc[3] = {L_THIGH, L_LEG, L_FOOT}, jp[3] = {L_TORSO, L_THIGH, L_LEG};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);  // ctrlrange +-1 (xml:37-39)
-        const R tau = (R)m.gear[k] * c - (R)m.damp[k] * v[3 + k];
+        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] -= tau;
         f[jp[k]] += tau;
-        const R e = (R)m.arm[k] + hd * (R)m.damp[k];  // armature + implicit damping on theta_k
+        const R e = (R)kGeom.arm[k] + hd * (R)kGeom.damp[k];  // armature + implicit damping on theta_k
         A[jc[k]][jc[k]] += e;
         A[jp[k]][jp[k]] += e;
         A[jp[k]][jc[k]] -= e;  // parent index > child index: lower triangle
@@ -157,8 +207,8 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
         constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];  // C < P
         const R th = q[3 + k];
         R dist = R(0), J = R(0);
-        if (th - (R)m.lo[k] < R(0)) dist = th - (R)m.lo[k], J = R(1);
-        else if ((R)m.hi[k] - th < R(0)) dist = (R)m.hi[k] - th, J = R(-1);
+        if (th - (R)kGeom.lo[k] < R(0)) dist = th - (R)kGeom.lo[k], J = R(1);
+        else if ((R)kGeom.hi[k] - th < R(0)) dist = (R)kGeom.hi[k] - th, J = R(-1);
         if (J != R(0)) {
             R y[NV], yd[NV];
 #pragma unroll
@@ -168,7 +218,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             R Aii = R(0), acur = R(0);
 #pragma unroll
             for (int i = C; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
-            const R imp = impedance(dist, (R)m.l_dmin, (R)m.l_dmax, (R)m.l_width);
+            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = div_r(R(1) - imp, imp) * Aii;
             const R force = div_r(aref - acur, Aii + Rr);
@@ -181,7 +231,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
     // link origins (world): torso, then down the chain
     V2<R> org[NL];
-    org[L_TORSO] = V2<R>{q[0], (R)m.z0 + q[1]};
+    org[L_TORSO] = V2<R>{q[0], (R)kGeom.z0 + q[1]};
     org[L_THIGH] = V2<R>{org[L_TORSO].x + D[L_TORSO].x, org[L_TORSO].z + D[L_TORSO].z};
     org[L_LEG] = V2<R>{org[L_THIGH].x + D[L_THIGH].x, org[L_THIGH].z + D[L_THIGH].z};
     org[L_FOOT] = V2<R>{org[L_LEG].x + D[L_LEG].x, org[L_LEG].z + D[L_LEG].z};
@@ -192,9 +242,9 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     // one capsule end sphere against the floor; geom order torso, thigh, leg, foot (two ends each)
     auto contact = [&](auto pt_c) __attribute__((always_inline)) {
         constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
-        const V2<R> e = rot(cs[LNK], sn[LNK], (R)m.geom_end[pt][0], (R)m.geom_end[pt][1]);
-        const R dist = org[LNK].z + e.z - (R)m.radius[gi];
-        if (dist < (R)m.margin) {
+        const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+        const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
+        if (dist < (R)kGeom.margin) {
             // contact point midway between the surfaces: p = (s.x, dist/2); r = p - link origin
             const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
             R Jx[NV], Jz[NV];
@@ -217,13 +267,13 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 Ann = fma_r(Jz[i], dz[i], Ann), Att = fma_r(Jx[i], dx[i], Att), Atn = fma_r(Jx[i], dz[i], Atn);
                 an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
             }
-            const R pos = dist - (R)m.margin;
-            const R imp = impedance(pos, (R)m.c_dmin, (R)m.c_dmax, (R)m.c_width);
+            const R pos = dist - (R)kGeom.margin;
+            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
             const R k1 = div_r(R(1) - imp, imp);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - an, Ann + k1 * Ann);
             if (fn > R(0)) {
                 R ft = div_r(-(R)m.cB * vt - at - Atn * fn, Att + k1 * Att);
-                const R lim = (R)m.friction[gi] * fn;
+                const R lim = (R)kGeom.friction[gi] * fn;
                 ft = ft > lim ? lim : (ft < -lim ? -lim : ft);
 #pragma unroll
                 for (int i = LNK; i < NV; ++i) z[i] = fma_r(dz[i], fn, fma_r(dx[i], ft, z[i]));
@@ -242,53 +292,6 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     // ---- back to joint coordinates
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[L_TORSO];
     qacc[3] = acc[L_TORSO] - acc[L_THIGH], qacc[4] = acc[L_THIGH] - acc[L_LEG], qacc[5] = acc[L_LEG] - acc[L_FOOT];
-}
-
-// host: model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000)
-inline Model make_model(double dt) {
-    using namespace cheetah::cheetah_host;
-    Model m;
-    memset(&m, 0, sizeof(m));
-    const double rho = 1000.0, deg = M_PI / 180.0;
-    // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
-    // foot (0,.1) xml:29, leg (0,.6) :25, thigh (0,1.05) :21, torso (0,1.25) :17
-    const double half[NL] = {0.195, 0.25, 0.225, 0.2}, rad[NL] = {0.06, 0.04, 0.05, 0.05};  // capsules :30,26,22,18
-    const H2 gc[NL] = {{0.065, 0}, {0, -0.25}, {0, -0.225}, {0, 0}};     // capsule centres, link frame
-    const double gang[NL] = {M_PI / 2, 0, 0, 0};                          // foot capsule lies along x
-    const H2 dvec[NL] = {{0, 0}, {0, -0.5}, {0, -0.45}, {0, -0.2}};       // to the child joint
-    double mass[NL], inertia[NL], sub[NL];
-    for (int b = 0; b < NL; ++b) {
-        mass[b] = capsule_mass(rho, rad[b], half[b]);
-        inertia[b] = capsule_inertia_perp(rho, rad[b], half[b]);
-        sub[b] = mass[b] + (b ? sub[b - 1] : 0.0);  // link b carries links 0..b-1
-    }
-    for (int b = 0; b < NL; ++b) {
-        const double carried = b ? sub[b - 1] : 0.0;
-        m.sx[b] = mass[b] * gc[b].x + carried * dvec[b].x, m.sz[b] = mass[b] * gc[b].z + carried * dvec[b].z;
-        m.diag[b] = inertia[b] + mass[b] * (gc[b].x * gc[b].x + gc[b].z * gc[b].z) +
-                    carried * (dvec[b].x * dvec[b].x + dvec[b].z * dvec[b].z);
-        m.d[b][0] = dvec[b].x, m.d[b][1] = dvec[b].z;
-    }
-    m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = 1.25 - 1.25;  // body pos z 1.25, rootz ref 1.25 (:16)
-    const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};  // :21,25,29
-    for (int k = 0; k < 3; ++k) m.damp[k] = 1.0, m.arm[k] = 1.0, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = 200.0;  // :5,37-39
-    const int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
-    for (int g = 0; g < 4; ++g) {
-        const int b = geom_link[g];
-        const H2 ax = hrot(gang[b], {0, 1});
-        m.geom_end[2 * g][0] = gc[b].x - half[b] * ax.x, m.geom_end[2 * g][1] = gc[b].z - half[b] * ax.z;
-        m.geom_end[2 * g + 1][0] = gc[b].x + half[b] * ax.x, m.geom_end[2 * g + 1][1] = gc[b].z + half[b] * ax.z;
-        m.radius[g] = rad[b];
-        m.friction[g] = g == 3 ? 2.0 : 1.0;  // max(floor 1.0, geom .9 | 2.0) (:18,22,26,30)
-    }
-    m.margin = 0.001;  // :6
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02;  // solref (.02 1), refsafe
-    m.c_dmin = 0.8, m.c_dmax = 0.8, m.c_width = 0.01;  // geom solimp (.8 .8 .01) :6
-    m.l_dmin = 0.9, m.l_dmax = 0.95, m.l_width = 0.001;  // MuJoCo's joint-limit defaults
-    m.cK = 1.0 / (m.c_dmax * m.c_dmax * tc * tc), m.cB = 2.0 / (m.c_dmax * tc);
-    m.lK = 1.0 / (m.l_dmax * m.l_dmax * tc * tc), m.lB = 2.0 / (m.l_dmax * tc);
-    m.dt = dt;
-    return m;
 }
 
 }  // namespace hopper
