@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def mean_counters(d, pat):
     agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # the newest pass only (gpurun_out/ accumulates earlier collections)
         for r in csv.DictReader(open(f)):
             if pat in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -28,7 +29,7 @@ def main():
     raw, rnd, workload, pat = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     n_envs, horizon, bytes_per_step, waves = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    stats = glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+    stats = sorted(glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(stats, os.path.join(ROOT, "profiles", f"{rnd}_{workload}_kernel_stats.csv"))
     krow = [r for r in csv.DictReader(open(stats)) if pat in r["Name"]][0]
     fetch = mean_counters(os.path.join(raw, "fetch"), pat).get("FETCH_SIZE")
