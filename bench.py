@@ -141,6 +141,7 @@ def main():
     ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream)
     for _ in range(a.steps):
         sr.run_pass()
+    sr.wait_gathers()  # the last passes' observation all-gathers (overlapped with the rollouts) are inside the timed region
     ev1.record()
     torch.cuda.synchronize()
     if dist:
@@ -178,7 +179,7 @@ def main():
         "config": {"workload": w["desc"], "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
                    "real_time_scale": w["dt"], "integrator": a.integrator or w.get("integrator", "euler"), "api": "emei_rollout (one launch per horizon, device auto-reset)",
                    "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
-                   "obs_allgather": "final obs of each pass over RCCL" if world > 1 else "n/a (1 GPU)"},
+                   "obs_allgather": "final obs of each pass over RCCL, on a dedicated stream under the next pass's rollout" if world > 1 else "n/a (1 GPU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": sr.kernel_name,
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes,

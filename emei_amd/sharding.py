@@ -106,7 +106,15 @@ class ShardedRollout:
         self.actions = synthetic_actions(self.env, self.horizon, self.n, self.rank, self.world, self.device, self.act_dim)
         self.out = self.engine.alloc_outputs(self.horizon)
         if self.world > 1:
-            self.gathered = torch.empty((self.world * self.n, self.obs_dim), dtype=torch.float32, device=self.device)
+            # The observation return overlaps the NEXT pass's rollout: the shard is copied to one of two
+            # staging buffers on the launch stream and all-gathered from there on a dedicated stream (xGMI
+            # transfers run under the kernel); events fence each buffer before it is reused two passes later.
+            shape = (self.world * self.n, self.obs_dim)
+            self.gathered = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._stage = [torch.empty((self.n, self.obs_dim), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._comm = torch.cuda.Stream(device=self.device)
+            self._comm_done = [None, None]
+            self._pass = 0
         torch.cuda.synchronize()
 
     def run_pass(self, record=False):
@@ -120,8 +128,28 @@ class ShardedRollout:
             self._events.append((e0, e1))
         final_obs = obs[-1]
         if self.world > 1:
-            final_obs = allgather_obs(final_obs, out=self.gathered)
+            k = self._pass & 1
+            self._pass += 1
+            main = torch.cuda.current_stream()
+            if self._comm_done[k] is not None:
+                main.wait_event(self._comm_done[k])  # the gather that last read this staging buffer has finished
+            self._stage[k].copy_(final_obs)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ready)
+                final_obs = allgather_obs(self._stage[k], out=self.gathered[k])
+                done = torch.cuda.Event()
+                done.record(self._comm)
+                self._comm_done[k] = done
         return final_obs
+
+    def wait_gathers(self):
+        """Make the launch stream wait for every outstanding observation all-gather."""
+        if self.world > 1:
+            for ev in self._comm_done:
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
 
     def mean_kernel_ms(self):
         torch.cuda.synchronize()
