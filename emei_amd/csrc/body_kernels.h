@@ -1,13 +1,14 @@
-// body_kernels.h — step / rollout / reset kernels shared by the multi-DoF MuJoCo-style bodies
-// (HalfCheetah-style 9-DoF body, InvertedDoublePendulum).  A `Body` type supplies the arithmetic:
+// body_kernels.h — step / rollout / reset kernels shared by the MuJoCo-backed bodies (HalfCheetah-style
+// 9-DoF body, Hopper, InvertedDoublePendulum, InvertedPendulum with a non-default integrator / noise).
+// The integrators (mujoco_env.py:70-79,86-97), the Gaussian init / observation noise (:98-104,:197-249),
+// the device reset and the LDS staging are generic and live here; a `Body` type supplies:
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
-//   struct Model;                                   // constants, passed by value as a kernel argument
+//   struct Model; make_model(dt)                    // run-time constants, passed by value as a kernel argument
 //   accel(q, v, ctrl, m, hd, qacc)                  // forward dynamics incl. soft constraints; `hd` = dt when
 //                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0
 //   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal)   // obs / reward / terminal of a finished step
-// The integrators (mujoco_env.py:70-79,86-97), the Gaussian init / observation noise (:98-104,
-// :197-249) and the device reset are generic and live here.
+//   init_base(s)                                    // non-zero entries of init_qpos (added after the init noise)
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
