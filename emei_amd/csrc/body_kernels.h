@@ -230,17 +230,28 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
             }
         }
     };
-    fetch_actions(0);
+    // a one-float action is already one coalesced dword per lane: no staging, fetched a step ahead
+    float a_next = 0.f;
+    if constexpr (NA == 1) {
+        if (active) a_next = a.actions[i];
+    } else {
+        fetch_actions(0);
+    }
     for (int t = 0; t < a.n_steps; ++t) {
-        // stage this step's actions through LDS, then prefetch the next step's block
-#pragma unroll
-        for (int c = 0; c < kActIt; ++c) ((float4*)act_s[wv])[c * kWave + lane] = av[c];
-        wave_lds_fence();  // other lanes' vectors hold this lane's action
         R ctrl[NA];
+        if constexpr (NA == 1) {
+            ctrl[0] = (R)a_next;
+            if (active && t + 1 < a.n_steps) a_next = a.actions[(int64_t)(t + 1) * n + i];
+        } else {
+            // stage this step's actions through LDS, then prefetch the next step's block
 #pragma unroll
-        for (int k = 0; k < NA; ++k) ctrl[k] = (R)act_s[wv][lane * NA + k];
-        wave_lds_fence();  // the block is consumed before the next step overwrites it
-        if (t + 1 < a.n_steps) fetch_actions(t + 1);
+            for (int c = 0; c < kActIt; ++c) ((float4*)act_s[wv])[c * kWave + lane] = av[c];
+            wave_lds_fence();  // other lanes' vectors hold this lane's action
+#pragma unroll
+            for (int k = 0; k < NA; ++k) ctrl[k] = (R)act_s[wv][lane * NA + k];
+            wave_lds_fence();  // the block is consumed before the next step overwrites it
+            if (t + 1 < a.n_steps) fetch_actions(t + 1);
+        }
 
         R pre[NS];
 #pragma unroll
