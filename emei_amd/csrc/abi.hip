@@ -277,6 +277,7 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     memcpy(L.noise.init, h->cfg.init_sigma, sizeof(L.noise.init));
     memcpy(L.noise.obs, h->cfg.obs_sigma, sizeof(L.noise.obs));
     L.noise.shared = h->cfg.noise_layout == EMEI_NOISE_SHARED;
+    L.trig = h->trig;
     L.stream = (hipStream_t)stream;
     return L;
 }
@@ -557,6 +558,7 @@ extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs
     L.freq_rate = freq_rate;
     L.dt = real_time_scale;
     L.integrator = integrator;
+    L.trig = current_device_trig();
     L.stream = (hipStream_t)stream;
     int rc = body_launch(L);
     if (rc == EMEI_ERR_UNSUPPORTED)

@@ -5,9 +5,10 @@
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
 //   struct Model; make_model(dt)                    // run-time constants, passed by value as a kernel argument
-//   accel(q, v, ctrl, m, hd, qacc)                  // forward dynamics incl. soft constraints; `hd` = dt when
-//                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0
-//   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal)   // obs / reward / terminal of a finished step
+//   accel(q, v, ctrl, m, hd, qacc, trig)            // forward dynamics incl. soft constraints; `hd` = dt when
+//                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0;
+//                                                   // `trig` = the {sin,cos} table staged in LDS (emei_device.h)
+//   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal, trig)   // obs / reward / terminal of a finished step
 //   init_base(s)                                    // non-zero entries of init_qpos (added after the init noise)
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
@@ -89,7 +90,7 @@ __device__ __forceinline__ void body_init(typename Body::real (&s)[Body::NS], ui
 // F = (v, qacc(q, v)) with the full forward dynamics (constraints included) at every stage.
 template <class Body, bool RK4>
 __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS], const typename Body::real (&ctrl)[Body::NA],
-                                             const typename Body::Model& m, bool semi) {
+                                             const typename Body::Model& m, bool semi, const TrigCtx& trig) {
     using R = typename Body::real;
     constexpr int NV = Body::NS / 2;
     const R dt = (R)m.dt;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
 #pragma unroll
     for (int i = 0; i < NV; ++i) q[i] = s[i], v[i] = s[NV + i];
     if constexpr (!RK4) {
-        Body::accel(q, v, ctrl, m, dt, acc);
+        Body::accel(q, v, ctrl, m, dt, acc, trig);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const R vn = fma_r(dt, acc[i], v[i]);
@@ -110,7 +111,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
         for (int i = 0; i < NV; ++i) qs[i] = q[i], vs[i] = v[i], dq[i] = R(0), dv[i] = R(0);
 #pragma unroll 1
         for (int st = 0; st < 4; ++st) {
-            Body::accel(qs, vs, ctrl, m, R(0), acc);
+            Body::accel(qs, vs, ctrl, m, R(0), acc, trig);
             const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);
             const R h = dt * (st == 2 ? R(1) : R(0.5));  // step to the NEXT stage state
 #pragma unroll
@@ -150,6 +151,7 @@ struct BodyLaunch {
     double dt = 0.002;
     int32_t integrator = 0;
     NoiseSpec noise;
+    const void* trig = nullptr;
     hipStream_t stream = nullptr;
 };
 int body_launch(const BodyLaunch& L);  // body_dispatch.hip
@@ -170,6 +172,7 @@ struct BodyArgs {
     uint64_t seed, env_offset;
     int32_t semi;  // EMEI_INTEG_SEMI_IMPLICIT
     NoiseArgs<Body::NS> noise;
+    const SinCosEntry* trig;  // 256-entry {sin,cos} table of this device (abi.hip:emei_trig_table)
     typename Body::Model m;
 };
 
@@ -187,6 +190,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
     constexpr int kActIt = (kActVec + kWave - 1) / kWave, kObsIt = (kObsVec + kWave - 1) / kWave;
     __shared__ __attribute__((aligned(16))) float act_s[kWaves][kActIt * kWave * 4];
     __shared__ __attribute__((aligned(16))) float obs_s[kWaves][kObsIt * kWave * 4];
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, a.trig);  // every thread reaches the barrier: inactive lanes stay in the kernel
+    TrigCtx trig;
+    trig.tab = trig_s;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t n = a.n;
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
 #pragma unroll
         for (int k = 0; k < NS; ++k) pre[k] = s[k];
         for (int k = 0; k < a.freq_rate; ++k) {  // mujoco_env.py:91-104
-            body_substep<Body, RK4>(s, ctrl, a.m, a.semi != 0);
+            body_substep<Body, RK4>(s, ctrl, a.m, a.semi != 0, trig);
             if (obs_noise)
                 gauss_state<R, NS, false>(s, a.seed ^ kObsNoiseKey, a.env_offset + (uint64_t)i, episode,
                                           ((uint32_t)steps * (uint32_t)a.freq_rate + (uint32_t)k) * (uint32_t)((NS + 3) / 4),
@@ -266,7 +273,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
         float o[NO];
         R rew;
         bool term;
-        Body::outputs(s, pre, ctrl, a.m, a.freq_rate, o, rew, term);
+        Body::outputs(s, pre, ctrl, a.m, a.freq_rate, o, rew, term, trig);
         ++steps;
         const bool trunc = (a.max_episode_steps > 0) & (steps >= a.max_episode_steps);
         done = active ? ((term ? EMEI_DONE_TERMINAL : 0u) | (trunc ? EMEI_DONE_TRUNCATED : 0u)) : 0u;
@@ -396,10 +403,14 @@ __global__ void __launch_bounds__(kBlock)
 template <class Body, bool RK4>
 __global__ void __launch_bounds__(kBlock)
     body_next_obs_kernel(const float* obs, const float* actions, float* next_obs, int64_t n, int freq_rate, int semi,
-                         typename Body::Model m) {
+                         typename Body::Model m, const SinCosEntry* trig_tab) {
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
     static_assert(NS == NO, "observation and state must have the same layout");
+    __shared__ SinCosEntry trig_s[kTrigTableSize];
+    stage_trig_table(trig_s, trig_tab);
+    TrigCtx trig;
+    trig.tab = trig_s;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     R s[NS], pre[NS], ctrl[NA], rew;
@@ -407,10 +418,10 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < NS; ++k) s[k] = pre[k] = (R)obs[i * NO + k];
 #pragma unroll
     for (int k = 0; k < NA; ++k) ctrl[k] = (R)actions[i * NA + k];
-    for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0);
+    for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0, trig);
     float o[NO];
     bool term;
-    Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term);
+    Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term, trig);
 #pragma unroll
     for (int k = 0; k < NO; ++k) next_obs[i * NO + k] = o[k];
 }
@@ -429,6 +440,7 @@ static int launch_body(const BodyLaunch& L) {
             a.n = L.n, a.n_steps = L.n_steps, a.freq_rate = L.freq_rate, a.max_episode_steps = L.max_episode_steps;
             a.flags = L.flags, a.seed = L.seed, a.env_offset = L.env_offset, a.m = m;
             a.semi = L.integrator == EMEI_INTEG_SEMI_IMPLICIT, a.noise = NoiseArgs<Body::NS>(L.noise);
+            a.trig = (const SinCosEntry*)L.trig;
             if (L.integrator == EMEI_INTEG_RK4)
                 hipLaunchKernelGGL((body_rollout_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, a);
             else
@@ -458,10 +470,11 @@ static int launch_body(const BodyLaunch& L) {
             if constexpr (Body::kObsIsState) {
                 if (L.integrator == EMEI_INTEG_RK4)
                     hipLaunchKernelGGL((body_next_obs_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
-                                       L.obs_out, L.n, L.freq_rate, 0, m);
+                                       L.obs_out, L.n, L.freq_rate, 0, m, (const SinCosEntry*)L.trig);
                 else
                     hipLaunchKernelGGL((body_next_obs_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
-                                       L.obs_out, L.n, L.freq_rate, (int)(L.integrator == EMEI_INTEG_SEMI_IMPLICIT), m);
+                                       L.obs_out, L.n, L.freq_rate, (int)(L.integrator == EMEI_INTEG_SEMI_IMPLICIT), m,
+                                       (const SinCosEntry*)L.trig);
                 break;
             } else {
                 return EMEI_ERR_UNSUPPORTED;  // e.g. the double pendulum's observation "wrap" is not invertible

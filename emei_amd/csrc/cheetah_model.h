@@ -252,7 +252,7 @@ __device__ __forceinline__ void ldl_backward(const R (&A)[NV][NV], R (&x)[NV]) {
 // q, v in the reference's order (rootx, rootz, rooty, bthigh, bshin, bfoot, fthigh, fshin, ffoot).
 template <typename R>
 __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[6], const Model& m, R hd,
-                                      R (&qacc)[NV]) {
+                                      R (&qacc)[NV], const TrigCtx& trig) {
     // ---- absolute angles / rates, permuted link order: 0 bfoot 1 bshin 2 bthigh 3 ffoot 4 fshin 5 fthigh 6 torso
     R phi[7], om[7];
     phi[6] = q[2], om[6] = v[2];
@@ -264,7 +264,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     phi[3] = phi[4] + q[8], om[3] = om[4] + v[8];
     R cs[7], sn[7];
 #pragma unroll
-    for (int b = 0; b < 7; ++b) sincos_r(phi[b], sn[b], cs[b]);
+    for (int b = 0; b < 7; ++b) sincos_ctx(trig, phi[b], sn[b], cs[b]);
     V2<R> S[7];
 #pragma unroll
     for (int b = 0; b < 7; ++b) S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
@@ -493,13 +493,13 @@ struct CheetahBody {
     static Model make_model(double dt) { return cheetah::cheetah_make_model(dt); }
 
     __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
-                                                 const Model& m, R hd, R (&qacc)[cheetah::NV]) {
-        cheetah::accel(q, v, ctrl, m, hd, qacc);
+                                                 const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig) {
+        cheetah::accel(q, v, ctrl, m, hd, qacc, trig);
     }
     // obs = concat(qpos, qvel) (mujoco_env.py:153-155); reward half_cheetah.py:59-63 with step() semantics
     // (per env: w_f (x' - x)/dt_env - w_c sum a^2, dt_env = dt*freq_rate); terminal :65-67 (non-finite)
     __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
-                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term, const TrigCtx&) {
         R cost = R(0);
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);

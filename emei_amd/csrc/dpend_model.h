@@ -73,12 +73,12 @@ struct DPendBody {
 
     // q = (x, theta1, theta2), v = (v, omega1, omega2); no joint damping in this model, so `hd` is unused
     __device__ __forceinline__ static void accel(const R (&q)[3], const R (&v)[3], const R (&ctrl)[NA], const Model& m, R,
-                                                 R (&qacc)[3]) {
+                                                 R (&qacc)[3], const TrigCtx& trig) {
         const R phi1 = q[1] + (R)m.phi_off, phi2 = phi1 + q[2];
         const R w1 = v[1], w2 = v[1] + v[2];
         R s1, c1, s2, c2;
-        sincos_r(phi1, s1, c1);
-        sincos_r(phi2, s2, c2);
+        sincos_ctx(trig, phi1, s1, c1);
+        sincos_ctx(trig, phi2, s2, c2);
         // S_j = R(phi_j)(0, s_jz) = (s_jz sin, s_jz cos);  D = R(phi_1)(0, L1)
         const R S1x = (R)m.s1z * s1, S1z = (R)m.s1z * c1, S2x = (R)m.s2z * s2, S2z = (R)m.s2z * c2;
         const R Dx = (R)m.L1 * s1, Dz = (R)m.L1 * c1;
@@ -137,11 +137,12 @@ struct DPendBody {
         const T pi = T(3.141592653589793);
         return pymod_pos(th + pi, T(2), T(0.5)) * pi - pi;
     }
-    template <typename T>
-    __device__ __forceinline__ static void reward_terminal(const T (&o)[NO], const Model& m, T& rew, bool& term) {
+    // `sc(x, s, c)`: the caller's sincos (LDS table inside the rollout, polynomial in the stateless kernels)
+    template <typename T, typename SC>
+    __device__ __forceinline__ static void reward_terminal(const T (&o)[NO], const Model& m, T& rew, bool& term, SC sc) {
         T sa, ca, sb, cb;
-        sincos_r(o[1], sa, ca);
-        sincos_r(o[1] + o[2], sb, cb);
+        sc(o[1], sa, ca);
+        sc(o[1] + o[2], sb, cb);
         const T y = ca + cb;
         bool fin = true;
 #pragma unroll
@@ -153,9 +154,9 @@ struct DPendBody {
         else rew = (T(2) - y) / T(4) - (T(5e-3) * o[4] * o[4] + T(1e-4) * o[5] * o[5]), term = !(inx & fin);  // :183-196
     }
     __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
-                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term, const TrigCtx& trig) {
         R ob[NO] = {s[0], quirk_wrap(s[1]), quirk_wrap(s[2]), s[3], s[4], s[5]};
-        reward_terminal(ob, m, rew, term);
+        reward_terminal(ob, m, rew, term, [&](R x, R& sn, R& cs) { sincos_ctx(trig, x, sn, cs); });
 #pragma unroll
         for (int k = 0; k < NO; ++k) o[k] = (float)ob[k];
     }
@@ -169,7 +170,7 @@ struct DPendBody {
         bool term;
 #pragma unroll
         for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
-        reward_terminal(o, m, rew, term);
+        reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return rew;
     }
     __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
@@ -177,7 +178,7 @@ struct DPendBody {
         bool term;
 #pragma unroll
         for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
-        reward_terminal(o, m, rew, term);
+        reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return term;
     }
 };

@@ -136,7 +136,7 @@ __device__ __forceinline__ void ldl_backward(const R (&A)[NV][NV], R (&x)[NV]) {
 // Forward dynamics: qacc at (q, v); hd = dt for MuJoCo's Euler (implicit joint damping), 0 for RK4.
 template <typename R>
 __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
-                                      R (&qacc)[NV]) {
+                                      R (&qacc)[NV], const TrigCtx& trig) {
     // absolute angles / rates down the chain (hinges about -y)
     R phi[NL], om[NL];
     phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
@@ -147,7 +147,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     V2<R> S[NL], D[NL];
 #pragma unroll
     for (int b = 0; b < NL; ++b) {
-        sincos_r(phi[b], sn[b], cs[b]);
+        sincos_ctx(trig, phi[b], sn[b], cs[b]);
         S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
         D[b] = rot(cs[b], sn[b], (R)kGeom.d[b][0], (R)kGeom.d[b][1]);
         w2[b] = om[b] * om[b];
@@ -308,8 +308,8 @@ struct HopperBody {
     static Model make_model(double dt) { return hopper::make_model(dt); }
 
     __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
-                                                 R (&qacc)[6]) {
-        hopper::accel(q, v, ctrl, m, hd, qacc);
+                                                 R (&qacc)[6], const TrigCtx& trig) {
+        hopper::accel(q, v, ctrl, m, hd, qacc, trig);
     }
     // hopper.py:79-93 as executed: np.logical_and(healthy_state, healthy_z, healthy_angle) takes the
     // third argument as `out=`, so the angle range is never applied
@@ -324,7 +324,7 @@ struct HopperBody {
     // (is_healthy | terminate_when_unhealthy) * 1 = 1 for the default flag; + w_f (x' - x)/dt_env
     // - 1e-3 sum a^2 (per env, step() semantics).  terminal (:104-106) = ~(is_healthy | True) = False.
     __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
-                                                   int freq_rate, float (&o)[NO], R& rew, bool& term) {
+                                                   int freq_rate, float (&o)[NO], R& rew, bool& term, const TrigCtx&) {
         R cost = R(0);
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);

@@ -69,9 +69,9 @@ struct InvPendBody {
 
     // q = (x, theta), v = (xdot, omega); no joint damping in this model (`hd` unused)
     __device__ __forceinline__ static void accel(const R (&q)[2], const R (&v)[2], const R (&ctrl)[NA], const Model& m, R,
-                                                 R (&qacc)[2]) {
+                                                 R (&qacc)[2], const TrigCtx& trig) {
         R sn, cs;
-        sincos_r(q[1] + (R)m.phi_off, sn, cs);
+        sincos_ctx(trig, q[1] + (R)m.phi_off, sn, cs);
         const R M11 = (R)m.M11, M22 = (R)m.M22, M12 = (R)m.mpr * cs;
         const R u = ctrl[0] < (R)m.ctrl_lo ? (R)m.ctrl_lo : (ctrl[0] > (R)m.ctrl_hi ? (R)m.ctrl_hi : ctrl[0]);
         const R f1 = (R)m.gear * u + (R)m.mpr * sn * v[1] * v[1];
@@ -102,10 +102,11 @@ struct InvPendBody {
         const T pi = T(3.141592653589793);
         return pymod_pos(th + pi, T(2) * pi, T(1.0 / (2 * 3.141592653589793))) - pi;
     }
-    template <typename T>
-    __device__ __forceinline__ static void reward_terminal(const T (&o)[NO], const Model& m, T& rew, bool& term) {
+    // `sc(x, s, c)`: the caller's sincos (LDS table inside the rollout, polynomial in the stateless kernels)
+    template <typename T, typename SC>
+    __device__ __forceinline__ static void reward_terminal(const T (&o)[NO], const Model& m, T& rew, bool& term, SC sc) {
         T sn, y;
-        sincos_r(o[1], sn, y);
+        sc(o[1], sn, y);
         const bool fin = finite_r(o[0]) & finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
         const bool inx = ((T)m.x_lo < o[0]) & (o[0] < (T)m.x_hi);
         if (VARIANT == 0) rew = T(1), term = !((y >= T(0.9)) & fin);          // :73-79
@@ -114,9 +115,9 @@ struct InvPendBody {
         else rew = (T(1) - y) / T(2), term = !(inx & fin);                     // :174-183
     }
     __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&)[NS], const R (&)[NA], const Model& m, int,
-                                                   float (&o)[NO], R& rew, bool& term) {
+                                                   float (&o)[NO], R& rew, bool& term, const TrigCtx& trig) {
         R ob[NO] = {s[0], wrap(s[1]), s[2], s[3]};
-        reward_terminal(ob, m, rew, term);
+        reward_terminal(ob, m, rew, term, [&](R x, R& sn, R& cs) { sincos_ctx(trig, x, sn, cs); });
 #pragma unroll
         for (int k = 0; k < NO; ++k) o[k] = (float)ob[k];
     }
@@ -127,13 +128,13 @@ struct InvPendBody {
     __device__ __forceinline__ static double batch_reward(const float* obs, const float*, const float*, const Model& m, int) {
         double o[NO] = {obs[0], obs[1], obs[2], obs[3]}, rew;
         bool term;
-        reward_terminal(o, m, rew, term);
+        reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return rew;
     }
     __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
         double o[NO] = {obs[0], obs[1], obs[2], obs[3]}, rew;
         bool term;
-        reward_terminal(o, m, rew, term);
+        reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return term;
     }
 };
