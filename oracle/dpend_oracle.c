@@ -153,6 +153,21 @@ EXPORT void dpend_oracle_step(int variant, int64_t n, int freq_rate, double dt, 
     dpend_oracle_step_ex(variant, n, freq_rate, dt, state, action, obs, reward, terminal, NULL);
 }
 
+/* The same smooth dynamics with caller-supplied parameters (cart mass, pole mass, pole inertia about its
+ * com, com distance, pole-1 length, gravity), generalized forces on (x, theta1, theta2) instead of the
+ * actuator, no limit: used by the tests to compare
+ * the equations of motion with the reference's own SymPy derivation (auxiliary/lagrange_eqs.py). */
+EXPORT void dpend_oracle_accel_custom(double mc, double mp, double Ip, double lc, double L1, double g, const double* q,
+                                      const double* v, const double* gen_force, double* acc) {
+    dp_model_t m;
+    memset(&m, 0, sizeof(m));
+    m.mc = mc, m.mp = mp, m.Ip = Ip, m.lc = lc, m.L1 = L1, m.gx = 0.0, m.gz = g;
+    double M[3][3], bias[3], rhs[3];
+    dp_dynamics(&m, 0.0, q, v, M, bias);
+    rhs[0] = gen_force[0] - bias[0], rhs[1] = gen_force[1] - bias[1], rhs[2] = gen_force[2] - bias[2];
+    solve3(M, rhs, acc);
+}
+
 EXPORT void dpend_oracle_reward_terminal(int variant, int64_t n, const double* obs, double* reward, uint8_t* terminal) {
     for (int64_t i = 0; i < n; ++i) dp_reward_terminal(variant, obs + 6 * i, reward + i, terminal + i);
 }

@@ -352,6 +352,20 @@ EXPORT void emei_oracle_ip_step_ex(int variant, int64_t n, int freq_rate, double
     }
 }
 
+/* The same smooth dynamics with caller-supplied parameters (cart mass, pole mass, com distance, inertia about
+ * the com, gravity), a plain force instead of gear * clipped ctrl and no slider limit: used by the tests to
+ * compare the equations of motion with the reference's own SymPy derivation (auxiliary/lagrange_eqs.py). */
+EXPORT void emei_oracle_ip_accel_custom(double mc, double mp, double r, double Icom, double g, const double* q,
+                                        const double* v, double force, double* acc) {
+    ip_model_t m;
+    memset(&m, 0, sizeof(m));
+    m.mc = mc, m.mp = mp, m.r = r, m.Icom = Icom, m.phi0 = 0.0, m.g = g;
+    m.gear = 1.0, m.ctrl_lo = -INFINITY, m.ctrl_hi = INFINITY, m.x_lo = -INFINITY, m.x_hi = INFINITY;
+    m.timeconst = 0.02, m.dampratio = 1.0, m.dmin = 0.9, m.dmax = 0.95, m.width = 0.001, m.invweight_slider = 1.0;
+    ip_ctx_t ctx = {&m, 0};
+    ip_accel(&ctx, 0.02, 0.0, q, v, &force, acc);
+}
+
 EXPORT void emei_oracle_ip_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
                                 double* obs, double* reward, uint8_t* terminal) {
     emei_oracle_ip_step_ex(variant, n, freq_rate, dt, state, action, obs, reward, terminal, NULL);

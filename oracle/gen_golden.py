@@ -475,6 +475,65 @@ def gen_hopper_firstparty(ref, out):
     return data
 
 
+def gen_lagrange(ref_root, out):
+    """Equations of motion of the cart + n-pole chain from the reference's own derivation tool
+    (emei/envs/classic_control/auxiliary/lagrange_eqs.py:12-69, SymPy Lagrangian; uniform rods of half-length
+    l_i, inertia m l^2 / 3 about the centre, pole i+1 hinged at the tip of pole i, angles from the upright,
+    relative joint angles): accelerations for random parameters / states / forces, n = 1 and n = 2.  They pin
+    the STRUCTURE of the oracle's InvertedPendulum / InvertedDoublePendulum dynamics (evaluated with rod
+    parameters instead of the xml's capsules) to first-party reference code."""
+    import importlib.util
+    import types
+
+    import sympy as sp
+
+    ipy, disp = types.ModuleType("IPython"), types.ModuleType("IPython.display")
+    disp.display, disp.Latex = (lambda *a, **k: None), object
+    sys.modules.setdefault("IPython", ipy)
+    sys.modules.setdefault("IPython.display", disp)
+    path = os.path.join(ref_root, "emei", "envs", "classic_control", "auxiliary", "lagrange_eqs.py")
+    spec = importlib.util.spec_from_file_location("emei_lagrange_eqs", path)
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)  # the unmodified reference file
+    data = {}
+    rng = np.random.default_rng(2024)
+    for n in (1, 2):
+        eqs, dyn = L.cartpole(n)
+        t = sp.Symbol("t")
+        q = sp.symbols(f"q0:{n + 1}")
+        v = sp.symbols(f"v0:{n + 1}")
+        a = sp.symbols(f"a0:{n + 1}")
+        rep = []
+        for k, f in enumerate(dyn):
+            rep.append((sp.diff(f, t, 2), a[k]))
+        for k, f in enumerate(dyn):
+            rep.append((sp.diff(f, t), v[k]))
+        for k, f in enumerate(dyn):
+            rep.append((f, q[k]))
+        exprs = [e.subs(rep) for e in eqs]
+        A, b = sp.linear_eq_to_matrix(exprs, list(a))
+        params = [sp.Symbol("g", real=True), sp.Symbol("F", real=True), sp.Symbol("M", real=True)] \
+            + list(sp.symbols(f"m:{n}", real=True)) + list(sp.symbols(f"l:{n}", real=True))
+        fn = sp.lambdify(params + list(q) + list(v), (A, b), "numpy")
+        B = 96
+        g = np.full(B, 9.81)
+        F = rng.uniform(-300, 300, B)
+        M = rng.uniform(1.0, 12.0, B)
+        m0 = rng.uniform(0.5, 6.0, B)
+        l0 = rng.uniform(0.1, 0.5, B)
+        ms, ls = [m0] * n, [l0] * n  # identical poles (the xml's two poles are identical, :35-38)
+        qs = np.column_stack([rng.uniform(-2, 2, B)] + [rng.uniform(-np.pi, np.pi, B) for _ in range(n)])
+        vs = np.column_stack([rng.normal(0, 2, B)] + [rng.normal(0, 5, B) for _ in range(n)])
+        acc = np.empty((B, n + 1))
+        for i in range(B):
+            Ai, bi = fn(g[i], F[i], M[i], *[x[i] for x in ms], *[x[i] for x in ls], *qs[i], *vs[i])
+            acc[i] = np.linalg.solve(np.asarray(Ai, float), np.asarray(bi, float).reshape(-1))
+        data[f"n{n}_g"], data[f"n{n}_F"], data[f"n{n}_M"], data[f"n{n}_m"], data[f"n{n}_l"] = g, F, M, m0, l0
+        data[f"n{n}_q"], data[f"n{n}_v"], data[f"n{n}_acc"] = qs, vs, acc
+    np.savez_compressed(os.path.join(out, "lagrange_golden.npz"), **data)
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -486,12 +545,13 @@ def main():
     m = gen_mujoco_firstparty(ref, a.out)
     d = gen_dpend_firstparty(ref, a.out)
     h = gen_hopper_firstparty(ref, a.out)
+    lg = gen_lagrange(a.ref, a.out)
     env = ref.cp.CartPoleSwingUpEnv()
     o, _ = env.reset(seed=0)
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h))
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg))
 
 
 if __name__ == "__main__":

@@ -211,6 +211,16 @@ def ip_step(variant, state, action, freq_rate=1, dt=0.02, opt=None):
     return st, obs, rew, term.astype(bool)
 
 
+def ip_accel_custom(mc, mp, r, Icom, g, q, v, force):
+    """(x'', theta'') of the oracle's cart + pole equations with caller-supplied parameters (no gear, no limit)."""
+    q = np.ascontiguousarray(q, np.float64).reshape(2)
+    v = np.ascontiguousarray(v, np.float64).reshape(2)
+    acc = np.empty(2)
+    lib().emei_oracle_ip_accel_custom(C.c_double(mc), C.c_double(mp), C.c_double(r), C.c_double(Icom), C.c_double(g),
+                                      _p(q, C.c_double), _p(v, C.c_double), C.c_double(force), _p(acc, C.c_double))
+    return acc
+
+
 def ip_reward(variant, obs):
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 4)
     out = np.empty(obs.shape[0])
@@ -343,6 +353,18 @@ def dpend_step(variant, state, action, freq_rate=1, dt=0.02, opt=None):
                                _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double),
                                _p(term, C.c_uint8), _o(opt))
     return st, obs, rew, term.astype(bool)
+
+
+def dpend_accel_custom(mc, mp, Ip, lc, L1, g, q, v, gen_force):
+    """(x'', theta1'', theta2'') of the oracle's cart + two-pole equations with caller-supplied parameters and
+    generalized forces (on x, theta1, theta2)."""
+    q = np.ascontiguousarray(q, np.float64).reshape(3)
+    v = np.ascontiguousarray(v, np.float64).reshape(3)
+    f = np.ascontiguousarray(gen_force, np.float64).reshape(3)
+    acc = np.empty(3)
+    lib().dpend_oracle_accel_custom(C.c_double(mc), C.c_double(mp), C.c_double(Ip), C.c_double(lc), C.c_double(L1),
+                                    C.c_double(g), _p(q, C.c_double), _p(v, C.c_double), _p(f, C.c_double), _p(acc, C.c_double))
+    return acc
 
 
 def dpend_reward_terminal(variant, obs):

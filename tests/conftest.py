@@ -30,6 +30,11 @@ def hopper_golden():
     return np.load(os.path.join(GOLDEN, "hopper_firstparty_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def lagrange_golden():
+    return np.load(os.path.join(GOLDEN, "lagrange_golden.npz"))
+
+
 def rel_err(a, b, floor=1.0):
     """max |a-b| / max(|b|, floor) ignoring rows where both are NaN."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
