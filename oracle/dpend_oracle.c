@@ -6,7 +6,9 @@
  * emei/envs/mujoco/assets/inverted_double_pendulum.xml.  Dynamics parity with libmujoco is
  * UNPINNED (mujoco >= 2.2.0 is absent from the image); the first-party pieces — the quirky
  * observation "wrap" (:59), the four reward/terminal functions (:84-196) — are pinned by
- * tests/golden/dpend_firstparty_golden.npz.
+ * tests/golden/dpend_firstparty_golden.npz, and the smooth equations of motion (dp_dynamics) are pinned
+ * to the reference's own SymPy derivation (auxiliary/lagrange_eqs.py) by tests/golden/lagrange_golden.npz
+ * (tests/test_oracle_lagrange.py); capsule inertias, the soft limit and the integrators stay unpinned.
  *
  * Formulation (deliberately different from the HIP kernel's absolute-angle closed form): joint
  * coordinates q = (x, th1, th2); inertia matrix M = sum_b m_b Jc_b^T Jc_b + I_b Jw_b^T Jw_b from the

@@ -17,7 +17,9 @@
  *     this 2-DoF model (inertia-from-geom of the capsules in assets/inverted_pendulum.xml:12-23,
  *     CRBA/RNE closed form, explicit Euler on qvel, the soft joint-limit constraint of the
  *     "Computation" chapter) combined with emei's forward-Euler position override
- *     (emei/envs/mujoco/mujoco_env.py:86-109, 169-195).
+ *     (emei/envs/mujoco/mujoco_env.py:86-109, 169-195).  The smooth equations of motion themselves
+ *     (ip_accel without the limit) ARE pinned to the reference's own SymPy derivation
+ *     (classic_control/auxiliary/lagrange_eqs.py) by tests/golden/lagrange_golden.npz.
  *
  * Every function cites the reference file:line it follows.
  */
