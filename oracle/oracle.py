@@ -302,8 +302,19 @@ def planar_geometry(body, q):
     q = np.ascontiguousarray(q, np.float64).reshape(nv)
     mass = np.empty(nb)
     ends = np.empty((ng, 2, 2))
-    lib().planar_oracle_geometry(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(mass, C.c_double), _p(ends, C.c_double))
+    lib().planar_oracle_geometry(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(mass, C.c_double), _p(ends, C.c_double),
+                                 None, None, None)
     return mass, ends
+
+
+def planar_bodies(body, q):
+    """(mass [nb], com [nb,2] world, absolute angle [nb], inertia about the com [nb]) of every body at q."""
+    nb, ng, nv = {"cheetah": (7, 8, 9), "hopper": (4, 4, 6)}[body]
+    q = np.ascontiguousarray(q, np.float64).reshape(nv)
+    mass, ends, com, phi, inertia = np.empty(nb), np.empty((ng, 2, 2)), np.empty((nb, 2)), np.empty(nb), np.empty(nb)
+    lib().planar_oracle_geometry(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(mass, C.c_double), _p(ends, C.c_double),
+                                 _p(com, C.c_double), _p(phi, C.c_double), _p(inertia, C.c_double))
+    return mass, com, phi, inertia
 
 
 # --------------------------------------------------------------------------- Hopper (C)

@@ -464,13 +464,20 @@ EXPORT void planar_oracle_inertia(int body, const double* q, const double* v, do
 EXPORT void cheetah_oracle_inertia(const double* q, const double* v, double* M_out, double* bias_out, double* energy_out) {
     planar_oracle_inertia(0, q, v, M_out, bias_out, energy_out);
 }
-/* body masses / world contact-sphere centres at q, for geometry checks in the tests */
-EXPORT void planar_oracle_geometry(int body, const double* q, double* mass_out, double* ends_out /* [ng][2][2] */) {
+/* body masses / world contact-sphere centres at q, for geometry checks in the tests; optionally (non-NULL)
+ * each body's centre of mass [nb][2], absolute angle [nb] and inertia about the com [nb] */
+EXPORT void planar_oracle_geometry(int body, const double* q, double* mass_out, double* ends_out /* [ng][2][2] */,
+                                   double* com_out, double* phi_out, double* inertia_out) {
     planar_model_t m;
     if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
     kin_t k;
     kinematics(&m, q, &k);
-    for (int b = 0; b < m.nb; ++b) mass_out[b] = m.mass[b];
+    for (int b = 0; b < m.nb; ++b) {
+        mass_out[b] = m.mass[b];
+        if (com_out) com_out[2 * b] = k.com[b].x, com_out[2 * b + 1] = k.com[b].z;
+        if (phi_out) phi_out[b] = k.phi[b];
+        if (inertia_out) inertia_out[b] = m.inertia[b];
+    }
     for (int g = 0; g < m.ng; ++g)
         for (int e = 0; e < 2; ++e) {
             v2 s = add(k.org[m.geom_body[g]], rot(k.phi[m.geom_body[g]], m.geom_end[g][e]));

@@ -72,6 +72,27 @@ def test_inertia_matrix_and_bias_satisfy_lagrange(body, nv, stiff):
         assert np.abs(c - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("body,nv,arm,stiff", [("hopper", 6, [0, 0, 0, 1, 1, 1.0], np.zeros(6)),
+                                                ("cheetah", 9, [0, 0, 0] + [0.1] * 6, np.array([0, 0, 0, 240, 180, 120, 180, 120, 60.0]))])
+def test_energy_from_body_kinematics_matches_the_inertia_matrix(body, nv, arm, stiff):
+    """Independent of the recursive Newton-Euler code: kinetic energy summed over the bodies,
+    1/2 m |d com/dt|^2 + 1/2 I (d phi/dt)^2 with the time derivatives taken by central differences of the
+    kinematics along q + h v (+ the armature term), must equal 1/2 v^T M v; potential energy = sum m g z_com."""
+    rng = np.random.default_rng(8)
+    for _ in range(4):
+        q, v = rng.normal(0, 0.5, nv), rng.normal(0, 2.0, nv)
+        M, _, E = O.planar_inertia(body, q, v)
+        h = 1e-6
+        m, cp, pp, I = O.planar_bodies(body, q + h * v)
+        _, cm, pm, _ = O.planar_bodies(body, q - h * v)
+        _, c0, _, _ = O.planar_bodies(body, q)
+        vc, w = (cp - cm) / (2 * h), (pp - pm) / (2 * h)
+        T = 0.5 * np.sum(m * (vc ** 2).sum(axis=1)) + 0.5 * np.sum(I * w ** 2) + 0.5 * np.sum(np.asarray(arm) * v ** 2)
+        U = np.sum(m * 9.81 * c0[:, 1]) + 0.5 * np.sum(stiff * q ** 2)
+        assert abs(T - (0.5 * v @ M @ v + 0.5 * np.sum(np.asarray(arm) * v ** 2))) <= 1e-7 * T
+        assert abs((T + U) - E) <= 1e-7 * max(abs(E), 1.0)
+
+
 def test_free_flight_conserves_momentum_and_energy_order():
     """No contact, no limits active, zero control: the x momentum p_x = (M v)_0 is conserved, vertical
     momentum falls at m g, and the integration error of RK4 drops ~16x when dt halves."""
