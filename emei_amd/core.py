@@ -4,10 +4,18 @@ Reference behaviour kept (file:line under /root/reference/emei/core.py):
   * ``Freezable`` (:18-37): a ``frozen`` flag with assertions on double freeze / unfreeze.
   * ``OfflineEnv`` (:40-58): ``env_name`` = class name without the "Env" suffix, ``env_params_name`` =
     "&"-joined ``key=value`` pairs in sorted key order (the string test/test_core.py pins).
-    The download / h5 plumbing (:60-128) is a network fetch and is not part of the env-step path.
+    The download plumbing (:60-107) is a network fetch and is never performed; datasets are looked up
+    in the reference's directory scheme (``<root>/<env_name>/<env_params_name>/<dataset>``, :82-91) as
+    the ``.npz`` files ``emei_amd.datasets`` writes from GPU rollouts, with the key check of :118-126.
   * ``EmeiEnv`` (:131-193): causal-graph getters and the abstract batched functions.
 """
+import os
+import pathlib
+
 import numpy as np
+
+# core.py:15 of the reference; EMEI_DATASET_PATH relocates it (tests, shared filesystems)
+DATASET_PATH = pathlib.Path(os.environ.get("EMEI_DATASET_PATH", str(pathlib.Path.home() / ".emei" / "offline_data")))
 
 
 class Freezable:
@@ -42,8 +50,15 @@ class OfflineEnv:
         self._offline_dataset_names, self._offline_dataset_urls = [], {}
 
     @property
+    def dataset_dir(self) -> pathlib.Path:
+        """<root>/<env_name>/<env_params_name> (get_path_from_url, core.py:82-91)."""
+        return DATASET_PATH / self.env_name / self.env_params_name
+
+    @property
     def dataset_names(self):
-        return self._offline_dataset_names
+        """Datasets available for this (env, params): here the local files, never a URL table."""
+        d = self.dataset_dir
+        return sorted(p.stem for p in d.glob("*.npz")) if d.is_dir() else []
 
     @property
     def env_params_name(self):
@@ -51,10 +66,14 @@ class OfflineEnv:
         return "&".join(f"{k}={params[k]}" for k in sorted(params))
 
     def get_dataset(self, dataset_name):
-        raise NotImplementedError(
-            f"dataset {dataset_name!r}: the reference downloads datasets from the network (core.py:95-128), "
-            "which this build never does; generate one on the GPU with emei_amd.datasets.collect()"
-        )
+        """core.py:109-128 without the download: load `<dataset_dir>/<dataset_name>.npz` and run the same key check."""
+        assert dataset_name in self.dataset_names, (
+            f"dataset {dataset_name!r} not found under {self.dataset_dir}: this build never downloads "
+            "(core.py:95-107); generate one on the GPU with emei_amd.datasets.collect() + save_for_env()")
+        data = dict(np.load(self.dataset_dir / f"{dataset_name}.npz"))
+        for key in ["observations", "observations", "actions", "rewards", "dones", "timeouts"]:  # sic, core.py:118-126
+            assert key in data, "Dataset is missing key %s" % key
+        return data
 
 
 class EmeiEnv(Freezable, OfflineEnv):

@@ -80,6 +80,16 @@ def save_npz(dataset, path, rollout_info=None):
             json.dump(rollout_info, f, indent=4)
 
 
+def save_for_env(env, dataset, dataset_name, rollout_info=None):
+    """Write `dataset` where `env.get_dataset(dataset_name)` looks for it: the reference's directory scheme
+    <root>/<env_name>/<env_params_name>/<dataset_name> (core.py:82-91), as .npz."""
+    d = env.dataset_dir
+    d.mkdir(parents=True, exist_ok=True)
+    path = d / f"{dataset_name}.npz"
+    save_npz(dataset, path, rollout_info)
+    return path
+
+
 def load_npz(path):
     d = dict(np.load(path))
     for key in DATASET_KEYS:  # emei/core.py:118-126

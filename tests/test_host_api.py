@@ -145,3 +145,28 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_lib.EmeiHipError):
         emei_amd.CartPoleSwingUpEnv().reset(seed=0)
+
+
+def test_offline_dataset_lookup_is_local_only(tmp_path, monkeypatch):
+    """core.py:82-128: datasets live under <root>/<env_name>/<env_params_name>/; this build never downloads."""
+    from emei_amd import core, datasets
+
+    monkeypatch.setattr(core, "DATASET_PATH", tmp_path)
+    env = emei_amd.CartPoleSwingUpEnv(freq_rate=2)
+    assert env.dataset_dir == tmp_path / "CartPoleSwingUp" / "freq_rate=2&integrator=euler&real_time_scale=0.02"
+    assert env.dataset_names == []
+    with pytest.raises(AssertionError):  # `assert dataset_name in self._offline_dataset_urls`, core.py:110
+        env.get_dataset("uniform")
+    n = 32
+    data = {"observations": np.zeros((n, 4), np.float32), "next_observations": np.ones((n, 4), np.float32),
+            "actions": np.zeros((n, 1), np.float32), "rewards": np.zeros(n, np.float32), "dones": np.zeros(n, np.float32),
+            "timeouts": np.zeros(n, np.float32)}
+    path = datasets.save_for_env(env, data, "uniform", rollout_info={"total_sample_num": n})
+    assert path.exists() and env.dataset_names == ["uniform"]
+    got = env.get_dataset("uniform")
+    assert set(datasets.DATASET_KEYS) <= set(got) and np.array_equal(got["next_observations"], data["next_observations"])
+    bad = dict(data)
+    del bad["timeouts"]
+    datasets.save_for_env(env, bad, "broken")
+    with pytest.raises(AssertionError, match="Dataset is missing key timeouts"):  # core.py:118-126
+        env.get_dataset("broken")
