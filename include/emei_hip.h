@@ -3,8 +3,9 @@
  *
  * The reference (polixir/emei) has no FFI boundary: its "operator API" for this path is the Python
  * class surface.  Each entry point below names the reference interface it replaces (file:line under
- * /root/reference).  All pointers are caller-owned DEVICE pointers (e.g. torch.Tensor.data_ptr()),
- * contiguous, never retained past the call.  The library never allocates outputs, never
+ * /root/reference).  All pointers are caller-owned DEVICE-ACCESSIBLE pointers (device memory, e.g.
+ * torch.Tensor.data_ptr(), or pinned host memory mapped into the device address space), contiguous,
+ * never retained past the call.  The library never allocates outputs, never
  * synchronises the stream and never throws across the boundary.  `stream` is a hipStream_t passed
  * as void* (NULL = the default stream).  One handle <-> one device; a handle is not thread-safe,
  * distinct handles are.
