@@ -361,10 +361,11 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     auto limit = [&](auto kc) __attribute__((always_inline)) {  // joint limit on theta_k
         constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];  // child index < parent index
         const R th = q[3 + k];
-        R dist = R(0), J = R(0);
-        if (th - (R)kGeom.lo[k] < R(0)) dist = th - (R)kGeom.lo[k], J = R(1);
-        else if ((R)kGeom.hi[k] - th < R(0)) dist = (R)kGeom.hi[k] - th, J = R(-1);
-        if (J != R(0)) {
+        // lo < hi: at most one side is violated, the smaller of the two distances is it (branch-free pick)
+        const R dlo = th - (R)kGeom.lo[k], dhi = (R)kGeom.hi[k] - th;
+        const bool lower = dlo < dhi;
+        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
+        if (dist < R(0)) {
             R y[NV], yd[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) y[i] = R(0);

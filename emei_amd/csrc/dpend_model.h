@@ -109,10 +109,11 @@ struct DPendBody {
         R ax, a1_, a2_;
         solve(fx, f1, f2, ax, a1_, a2_);
         // soft slider limit with margin 0.01 (mjCNSTR_LIMIT_JOINT: active when dist < margin)
-        R dist = R(0), J = R(0);
-        if (q[0] - (R)m.x_lo < (R)m.margin) dist = q[0] - (R)m.x_lo, J = R(1);
-        else if ((R)m.x_hi - q[0] < (R)m.margin) dist = (R)m.x_hi - q[0], J = R(-1);
-        if (J != R(0)) {
+        // x_lo + margin < x_hi - margin: at most one side is active, the smaller distance is it
+        const R dlo = q[0] - (R)m.x_lo, dhi = (R)m.x_hi - q[0];
+        const bool lower = dlo < dhi;
+        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
+        if (dist < (R)m.margin) {
             R wx, w1_, w2_;
             solve(R(1), R(0), R(0), wx, w1_, w2_);
             const R pos = dist - (R)m.margin;

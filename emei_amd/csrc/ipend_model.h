@@ -79,10 +79,11 @@ struct InvPendBody {
         const R idet = rcp_r(fma_r(-M12, M12, M11 * M22));
         R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
         R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
-        R dist = R(0), J = R(0);  // soft slider limit
-        if (q[0] - (R)m.x_lo < R(0)) dist = q[0] - (R)m.x_lo, J = R(1);
-        else if ((R)m.x_hi - q[0] < R(0)) dist = (R)m.x_hi - q[0], J = R(-1);
-        if (J != R(0)) {
+        // soft slider limit; x_lo < x_hi: at most one side is violated, the smaller distance is it
+        const R dlo = q[0] - (R)m.x_lo, dhi = (R)m.x_hi - q[0];
+        const bool lower = dlo < dhi;
+        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
+        if (dist < R(0)) {
             const R xx = div_r(fabs(dist), (R)m.width);
             const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);

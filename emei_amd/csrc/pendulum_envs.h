@@ -202,13 +202,11 @@ struct InvPend {
         R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
         R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
         // soft slider-limit constraint (MuJoCo joint limit, default solref/solimp)
-        R dist = R(0), J = R(0);
-        if (x_old - (R)p.x_lo < R(0)) {
-            dist = x_old - (R)p.x_lo, J = R(1);
-        } else if ((R)p.x_hi - x_old < R(0)) {
-            dist = (R)p.x_hi - x_old, J = R(-1);
-        }
-        if (J != R(0)) {
+        // x_lo < x_hi: at most one side is violated, the smaller of the two distances is it (branch-free pick)
+        const R dlo = x_old - (R)p.x_lo, dhi = (R)p.x_hi - x_old;
+        const bool lower = dlo < dhi;
+        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
+        if (dist < R(0)) {
             R xx = div_r(fabs(dist), (R)p.width);
             R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
             R imp = (R)p.dmin + y * ((R)p.dmax - (R)p.dmin);
