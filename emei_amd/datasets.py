@@ -32,19 +32,42 @@ def random_actions(env, n_steps, generator=None):
     return (lo + (hi - lo) * u).float().contiguous()
 
 
-def collect(env, n_steps, actions=None, seed=0, device_rng=True):
+def collect(env, n_steps, actions=None, seed=0, device_rng=True, policy=None):
     """Roll every env of `env` (a vectorised emei_amd env) for n_steps with auto-reset and return
-    (dataset dict of torch tensors with N*n_steps rows, rollout_info dict like zoo/util.py:85-91)."""
+    (dataset dict of torch tensors with N*n_steps rows, rollout_info dict like zoo/util.py:85-91).
+
+    Actions: `actions` [T, N(, act_dim)] if given; else `policy(obs [N, obs_dim] float32 on the device) ->
+    actions [N(, act_dim)]` evaluated between steps (the agent.predict loop of zoo/util.py:54-59: one
+    emei_step launch per step, observations after a device reset rebuilt the same way); else uniform random
+    actions (`env.action_space.sample()`, zoo/util.py:58) in ONE fused rollout launch."""
     eng = env.engine
     N, T, od = eng.n_envs, int(n_steps), eng.obs_dim
     obs0, _ = env.reset(seed=seed, options={"device_rng": True} if device_rng else None)
     obs0 = torch.as_tensor(obs0, device=eng.device).reshape(N, od).float()
-    if actions is None:
-        g = torch.Generator(device=eng.device)
-        g.manual_seed(int(seed))
-        actions = random_actions(env, T, g)
     _, epi0 = eng.get_counters()
-    next_obs, rew, done = eng.rollout(actions, auto_reset=True)
+    if actions is None and policy is not None:
+        next_obs, rew, done = eng.alloc_outputs(T)
+        acts_t, cur, epi = [], obs0, epi0.clone()
+        for t in range(T):
+            a = policy(cur)
+            a = a.to(eng.device)
+            a = (a.to(torch.float32) if eng.act_dim else a.to(torch.int64)).contiguous()
+            acts_t.append(a)
+            eng.step(a, auto_reset=True, out=(next_obs[t], rew[t], done[t]))
+            cur = next_obs[t]
+            d = done[t] != 0
+            if bool(d.any()):  # the policy must see what reset() returned for the finished envs
+                epi = epi + d.to(torch.int64)
+                idx = torch.nonzero(d).reshape(-1)
+                cur = cur.clone()
+                cur[idx] = eng.episode_init_obs(idx, epi[idx])
+        actions = torch.stack(acts_t)
+    else:
+        if actions is None:
+            g = torch.Generator(device=eng.device)
+            g.manual_seed(int(seed))
+            actions = random_actions(env, T, g)
+        next_obs, rew, done = eng.rollout(actions, auto_reset=True)
     done_b = done != 0
     # observations[t] = next_observations[t-1], except right after a reset
     obs = torch.empty_like(next_obs)

@@ -64,3 +64,32 @@ def test_cheetah_dataset_shapes():
     assert data["observations"].shape == (1280, 18) and data["actions"].shape == (1280, 6) and info["total_episode_num"] == 0
     o, n = data["observations"].reshape(64, 20, 18), data["next_observations"].reshape(64, 20, 18)
     assert torch.equal(o[:, 1:], n[:, :-1]) and bool(torch.isfinite(n).all())
+
+
+def test_collect_with_a_policy_between_steps():
+    """zoo/util.py:54-59: actions come from agent.predict(obs) each step; a bang-bang 'policy' here."""
+    import emei_amd
+    from emei_amd import datasets
+
+    env = emei_amd.make("CartPoleBalancing-v0", num_envs=128, max_episode_steps=30, auto_reset=True)
+    seen = []
+
+    def policy(obs):
+        seen.append(obs.clone())
+        return (obs[:, 2] > 0).to(torch.int64)  # push towards the side the pole leans to
+
+    d, info = datasets.collect(env, 40, policy=policy, seed=3)
+    assert d["observations"].shape == (128 * 40, 4) and d["actions"].shape == (128 * 40, 1) and len(seen) == 40
+    o = d["observations"].reshape(128, 40, 4)
+    nxt = d["next_observations"].reshape(128, 40, 4)
+    dn = d["dones"].reshape(128, 40) != 0
+    # rows are true transitions: observations[t+1] == next_observations[t] unless step t ended an episode,
+    # where the policy saw (and the dataset holds) the initial observation of the next episode
+    cont = ~dn[:, :-1]
+    assert torch.equal(o[:, 1:][cont], nxt[:, :-1][cont])
+    assert bool((o[:, 1:][~cont].abs() <= 0.05 + 1e-6).all()) and bool(dn.any())  # cartpole.py:131-132: U(-0.05, 0.05)
+    for t in (0, 7, 39):
+        assert torch.equal(seen[t], o[:, t])
+    # the bang-bang controller keeps the pole up longer than random actions do
+    rnd, info_r = datasets.collect(emei_amd.make("CartPoleBalancing-v0", num_envs=128, max_episode_steps=30, auto_reset=True), 40, seed=3)
+    assert info["avg_length"] > info_r["avg_length"]
