@@ -191,7 +191,13 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (cfg->precision != EMEI_PRECISION_REF && cfg->precision != EMEI_PRECISION_F32)
         return fail(EMEI_ERR_INVALID, "emei_create: precision=%d", cfg->precision);
     if (cfg->max_episode_steps < 0) return fail(EMEI_ERR_INVALID, "emei_create: max_episode_steps < 0");
+    int prev_device = 0;
+    HIP_TRY(hipGetDevice(&prev_device));
     HIP_TRY(hipSetDevice(cfg->device));
+    struct RestoreDevice {  // emei_create leaves the caller's current device as it found it
+        int d;
+        ~RestoreDevice() { (void)hipSetDevice(d); }
+    } restore{prev_device};
 
     emei_env* h = new (std::nothrow) emei_env();
     if (!h) return fail(EMEI_ERR_INVALID, "emei_create: out of host memory");
@@ -240,6 +246,20 @@ extern "C" EMEI_API int emei_destroy(emei_env* h) {
     return EMEI_OK;
 }
 
+// One handle <-> one device: every launch of a handle goes to the CALLER's current device, so a handle used
+// while another device is current would touch memory of the wrong GPU.  Refused up front.
+static int wrong_device(const emei_env* h, const char* fn) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(EMEI_ERR_HIP, "%s: hipGetDevice failed", fn);
+    if (dev != h->cfg.device)
+        return fail(EMEI_ERR_INVALID, "%s: the handle belongs to device %d but device %d is current", fn, h->cfg.device, dev);
+    return EMEI_OK;
+}
+#define EMEI_ON_DEVICE(h, fn)                                  \
+    do {                                                        \
+        if (int rc_ = wrong_device((h), (fn))) return rc_;      \
+    } while (0)
+
 static PendLaunch pend_base(emei_env* h, void* stream) {
     PendLaunch L;
     L.env_id = h->cfg.env_id;
@@ -284,6 +304,7 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
 
 extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_reset: null handle");
+    EMEI_ON_DEVICE(h, "emei_reset");
     h->cfg.seed = seed;
     int rc;
     if (is_pend(h->cfg.env_id)) {
@@ -302,6 +323,7 @@ extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
 
 extern "C" EMEI_API int emei_set_state(emei_env* h, const double* state_aos, int reset_counters, void* stream) {
     if (!h || !state_aos) return fail(EMEI_ERR_INVALID, "emei_set_state: null argument");
+    EMEI_ON_DEVICE(h, "emei_set_state");
     int rc = launch_state_unpack(state_aos, h->state, h->cfg.precision, h->cfg.n_envs, h->state_dim, (hipStream_t)stream);
     if (rc != EMEI_OK) return fail(rc, "emei_set_state: launch failed");
     if (reset_counters) {
@@ -314,6 +336,7 @@ extern "C" EMEI_API int emei_set_state(emei_env* h, const double* state_aos, int
 
 extern "C" EMEI_API int emei_get_state(emei_env* h, double* state_aos, void* stream) {
     if (!h || !state_aos) return fail(EMEI_ERR_INVALID, "emei_get_state: null argument");
+    EMEI_ON_DEVICE(h, "emei_get_state");
     if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_get_state: call reset before using the state");
     int rc = launch_state_pack(h->state, state_aos, h->cfg.precision, h->cfg.n_envs, h->state_dim, (hipStream_t)stream);
     return rc == EMEI_OK ? rc : fail(rc, "emei_get_state: launch failed");
@@ -321,6 +344,7 @@ extern "C" EMEI_API int emei_get_state(emei_env* h, double* state_aos, void* str
 
 extern "C" EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream) {
     if (!h || !obs_aos) return fail(EMEI_ERR_INVALID, "emei_get_obs: null argument");
+    EMEI_ON_DEVICE(h, "emei_get_obs");
     if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_get_obs: call reset before using the state");
     if (is_pend(h->cfg.env_id)) {
         PendLaunch L = pend_base(h, stream);
@@ -338,6 +362,7 @@ extern "C" EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream)
 
 extern "C" EMEI_API int emei_freeze(emei_env* h, void* stream) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_freeze: null handle");
+    EMEI_ON_DEVICE(h, "emei_freeze");
     if (!h->has_state) return fail(EMEI_ERR_STATE, "emei_freeze: no state to freeze (call reset first)");
     const size_t n = (size_t)h->cfg.n_envs;
     hipStream_t s = (hipStream_t)stream;
@@ -350,6 +375,7 @@ extern "C" EMEI_API int emei_freeze(emei_env* h, void* stream) {
 
 extern "C" EMEI_API int emei_unfreeze(emei_env* h, void* stream) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_unfreeze: null handle");
+    EMEI_ON_DEVICE(h, "emei_unfreeze");
     if (!h->frozen) return fail(EMEI_ERR_STATE, "emei_unfreeze: env has not been frozen");
     const size_t n = (size_t)h->cfg.n_envs;
     hipStream_t s = (hipStream_t)stream;
@@ -374,6 +400,7 @@ static int check_action_dtype(const emei_env* h, int action_dtype) {
 extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* actions, int action_dtype, float* obs_out,
                             float* reward_out, uint8_t* done_out, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(EMEI_ERR_INVALID, "emei_rollout: null argument");
+    EMEI_ON_DEVICE(h, "emei_rollout");
     if (n_steps < 1) return fail(EMEI_ERR_INVALID, "emei_rollout: n_steps=%d < 1", n_steps);
     if (!h->has_state) return fail(EMEI_ERR_STATE, "Call reset before using step method.");  // base_control.py:67
     if (flags & ~EMEI_FLAG_AUTO_RESET) return fail(EMEI_ERR_INVALID, "emei_rollout: unknown flags 0x%x", flags);
@@ -411,12 +438,14 @@ extern "C" EMEI_API int emei_step(emei_env* h, const void* actions, int action_d
 
 extern "C" EMEI_API int emei_compact_done(emei_env* h, int32_t* idx_out, int32_t* count_out, void* stream) {
     if (!h || !idx_out || !count_out) return fail(EMEI_ERR_INVALID, "emei_compact_done: null argument");
+    EMEI_ON_DEVICE(h, "emei_compact_done");
     int rc = launch_compact_done(h->done_mask, h->cfg.n_envs, idx_out, count_out, (hipStream_t)stream);
     return rc == EMEI_OK ? rc : fail(rc, "emei_compact_done: launch failed");
 }
 
 extern "C" EMEI_API int emei_get_counters(emei_env* h, int32_t* steps_out, uint32_t* episode_out, void* stream) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_get_counters: null handle");
+    EMEI_ON_DEVICE(h, "emei_get_counters");
     const size_t n = (size_t)h->cfg.n_envs;
     hipStream_t s = (hipStream_t)stream;
     if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, h->steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -427,6 +456,7 @@ extern "C" EMEI_API int emei_get_counters(emei_env* h, int32_t* steps_out, uint3
 extern "C" EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const int64_t* env_index, const uint32_t* episode,
                                               float* obs_out, void* stream) {
     if (!h || !env_index || !episode || !obs_out) return fail(EMEI_ERR_INVALID, "emei_episode_init_obs: null argument");
+    EMEI_ON_DEVICE(h, "emei_episode_init_obs");
     if (count <= 0) return fail(EMEI_ERR_INVALID, "emei_episode_init_obs: count=%lld", (long long)count);
     int rc;
     if (is_pend(h->cfg.env_id)) {

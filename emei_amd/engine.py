@@ -32,6 +32,21 @@ def env_dims(env_name):
     return od.value, ad.value, sd.value
 
 
+def _on_device(method):
+    """Run an Engine method with the engine's device current (the C ABI refuses a handle used under another
+    current device); a plain call when it already is (the per-step path pays one integer compare)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *a, **k):
+        if torch.cuda.current_device() == self.device.index:
+            return method(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return method(self, *a, **k)
+
+    return wrapper
+
+
 def _sigmas(x, state_dim):
     """float -> the same sigma everywhere; (pos, vel) -> per half; a sequence of state_dim values as given."""
     half = state_dim // 2
@@ -88,9 +103,11 @@ class Engine:
             pass
 
     # -- state ---------------------------------------------------------------------------------
+    @_on_device
     def reset(self, seed=0):
         L.check(L.lib().emei_reset(self._h, int(seed) & (2**64 - 1), _stream()))
 
+    @_on_device
     def set_state(self, state, reset_counters=True):
         st = torch.as_tensor(state, dtype=torch.float64, device=self.device).contiguous()
         if tuple(st.shape) != (self.n_envs, self.state_dim):
@@ -98,19 +115,23 @@ class Engine:
         L.check(L.lib().emei_set_state(self._h, _ptr(st), int(bool(reset_counters)), _stream()))
         torch.cuda.current_stream().synchronize()  # `st` may be a temporary
 
+    @_on_device
     def get_state(self):
         out = torch.empty((self.n_envs, self.state_dim), dtype=torch.float64, device=self.device)
         L.check(L.lib().emei_get_state(self._h, _ptr(out), _stream()))
         return out
 
+    @_on_device
     def get_obs(self):
         out = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float64, device=self.device)
         L.check(L.lib().emei_get_obs(self._h, _ptr(out), _stream()))
         return out
 
+    @_on_device
     def freeze(self):
         L.check(L.lib().emei_freeze(self._h, _stream()))
 
+    @_on_device
     def unfreeze(self):
         L.check(L.lib().emei_unfreeze(self._h, _stream()))
 
@@ -128,6 +149,7 @@ class Engine:
             raise ValueError("actions must be contiguous")
         return _ACT_DTYPES[actions.dtype]
 
+    @_on_device
     def step(self, actions, auto_reset=False, out=None):
         """-> obs [N,obs_dim] f32, reward [N] f32, done [N] u8 (bit0 terminal, bit1 truncated)."""
         dt = self._check_actions(actions, ())
@@ -136,6 +158,7 @@ class Engine:
                                   L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
 
+    @_on_device
     def step_host(self, action, auto_reset=False):
         """The gym-style single-env call (`env.step(a)` of base_control.py:61-83 with host values in and out):
         actions and results live in pinned host memory that the kernels address directly, so a step is
@@ -160,6 +183,7 @@ class Engine:
         torch.cuda.current_stream().synchronize()
         return obs64_np, obs32_np, rew_np, done_np
 
+    @_on_device
     def rollout(self, actions, auto_reset=False, out=None):
         """actions [T,N(,act_dim)] -> obs [T,N,obs_dim] f32, reward [T,N] f32, done [T,N] u8; one launch."""
         T = int(actions.shape[0])
@@ -169,6 +193,7 @@ class Engine:
                                      L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
 
+    @_on_device
     def capture_step_graph(self, actions, auto_reset=False):
         """Capture one emei_step launch per row of `actions` [K, N(,act_dim)] into a hipGraph.
 
@@ -204,6 +229,7 @@ class Engine:
                 torch.empty(lead + (self.n_envs,), dtype=torch.float32, device=self.device),
                 torch.empty(lead + (self.n_envs,), dtype=torch.uint8, device=self.device))
 
+    @_on_device
     def get_counters(self):
         """(steps since reset int32 [N], episode index int64 [N])."""
         steps = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
@@ -211,6 +237,7 @@ class Engine:
         L.check(L.lib().emei_get_counters(self._h, _ptr(steps), _ptr(epi), _stream()))
         return steps, epi.to(torch.int64) & 0xFFFFFFFF
 
+    @_on_device
     def episode_init_obs(self, env_index, episode):
         """Initial observation of the device reset for (env, episode) pairs -> [count, obs_dim] float32."""
         env_index = env_index.to(device=self.device, dtype=torch.int64).contiguous()
@@ -220,6 +247,7 @@ class Engine:
             L.check(L.lib().emei_episode_init_obs(self._h, env_index.numel(), _ptr(env_index), _ptr(epi), _ptr(out), _stream()))
         return out
 
+    @_on_device
     def compact_done(self):
         """Sorted indices of the envs that were done at the last step (int32 tensor)."""
         idx = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)

@@ -7,8 +7,9 @@
  * torch.Tensor.data_ptr(), or pinned host memory mapped into the device address space), contiguous,
  * never retained past the call.  The library never allocates outputs, never
  * synchronises the stream and never throws across the boundary.  `stream` is a hipStream_t passed
- * as void* (NULL = the default stream).  One handle <-> one device; a handle is not thread-safe,
- * distinct handles are.
+ * as void* (NULL = the default stream).  One handle <-> one device: calls on a handle must be made with
+ * that device current (checked: EMEI_ERR_INVALID otherwise; emei_create itself restores the caller's
+ * current device).  A handle is not thread-safe, distinct handles are.
  *
  * Return value: 0 = ok, negative = error (EMEI_ERR_*); emei_last_error() gives a thread-local text.
  */
