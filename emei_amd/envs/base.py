@@ -21,7 +21,13 @@ class HipEnv(EmeiEnv):
     def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler",
                  num_envs: int = 1, precision: str = "ref", device: Optional[int] = None,
                  max_episode_steps: Optional[int] = None, auto_reset: bool = False, init_noise=0.0,
-                 env_index_offset: int = 0, obs_noise=0.0, noise_layout: Optional[str] = None):
+                 env_index_offset: int = 0, obs_noise=0.0, noise_layout: Optional[str] = None,
+                 render_mode: Optional[str] = None):
+        if render_mode is not None:
+            # base_control.py:15,21 / mujoco_env.py:33 accept "human" / "rgb_array"; pygame and the MuJoCo viewer
+            # are outside the env-step path
+            raise NotImplementedError(f"render_mode={render_mode!r}: rendering is not part of the HIP engine")
+        self.render_mode = None
         self.freq_rate = freq_rate
         self.real_time_scale = real_time_scale
         self.integrator = integrator

@@ -97,6 +97,9 @@ def test_spaces_and_registry():
         emei_amd.spec("Walker2dRunning-v0")  # registered by the reference, class never written (register_env.py:92-96)
     with pytest.raises(NotImplementedError):  # mujoco_env.py:78-79
         emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator="verlet")
+    assert emei_amd.make("CartPoleSwingUp-v0", render_mode=None).render_mode is None  # base_control.py:15
+    with pytest.raises(NotImplementedError):
+        emei_amd.make("HopperRunning-v0", render_mode="human")
     for integ in ("euler", "semi_implicit_euler", "rk4"):
         e = emei_amd.BoundaryInvertedPendulumBalancingEnv(integrator=integ, obs_noise_params=(1e-3, 2e-3))
         assert e.env_params_name == f"freq_rate=1&integrator={integ}&real_time_scale=0.02"  # mujoco_env.py:51
