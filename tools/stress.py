@@ -2,7 +2,7 @@
 """Randomised determinism soak (run on the GPU box): for random (env, precision, integrator, noise, n, T) a
 fused rollout with auto-reset must equal the same rollout cut into random chunks and equal a second identical
 run, bit for bit (obs, reward, done, final state, counters).  Catches races / uninitialised reads that the
-fixed-shape parity tests could miss.  Usage: python tools/stress.py [seconds]"""
+fixed-shape parity tests could miss.  Usage: python tools/stress.py [seconds] [big]"""
 import sys
 import time
 
@@ -14,14 +14,15 @@ from emei_amd import _lib as L  # noqa: E402
 from emei_amd.engine import Engine  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+big = len(sys.argv) > 2 and sys.argv[2] == "big"  # full-size shards and longer horizons (fewer cases)
 rng = np.random.default_rng(12345)
 names = sorted(L.ENV_IDS)
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
     name = names[rng.integers(len(names))]
     classic = name.startswith("CartPole")
-    n = int(rng.choice([1, 63, 64, 65, 200, 256, 1000, 4096, 5000]))
-    T = int(rng.choice([1, 3, 16, 17, 40, 64]))
+    n = int(rng.choice([65536, 100000, 131072] if big else [1, 63, 64, 65, 200, 256, 1000, 4096, 5000]))
+    T = int(rng.choice([33, 100, 250] if big else [1, 3, 16, 17, 40, 64]))
     kw = dict(freq_rate=int(rng.integers(1, 4)), precision=str(rng.choice(["ref", "f32"])), seed=int(rng.integers(1 << 30)),
               max_episode_steps=int(rng.choice([0, 5, 20])), env_index_offset=int(rng.integers(0, 1 << 20)))
     kw["real_time_scale"] = 0.02 if (classic or "Pendulum" in name) else 0.002
