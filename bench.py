@@ -75,8 +75,8 @@ def cpu_baseline(env, n, freq_rate, dt, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cartpole_swingup", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--horizon", type=int, default=None)

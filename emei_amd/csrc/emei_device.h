@@ -72,9 +72,13 @@ __device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, dou
     const double inv_step = 40.74366543152521;                                    // 256 / (2 pi)
     const double H1 = 1.5707963267948966 / 64, H2 = 6.123233995736766e-17 / 64;  // 2pi/256 = H1 + H2
     TrigPendingF64 p;
-    const double n = __builtin_rint(x * inv_step);
+    // nearest integer of x * inv_step without v_rndne + v_cvt: adding 1.5 * 2^52 leaves it in the low mantissa
+    // bits (|x * inv_step| < 2^31 is guaranteed by the |x| <= 1e6 range of the fast path)
+    const double magic = 6755399441055744.0;
+    const double shifted = __builtin_fma(x, inv_step, magic);
+    const double n = shifted - magic;
     const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)t.tab +
-                          (((uint32_t)(int)n & (uint32_t)(kTrigTableSize - 1)) << 4);
+                          (((uint32_t)__double2loint(shifted) & (uint32_t)(kTrigTableSize - 1)) << 4);
     asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
     double r = __builtin_fma(-n, H1, x);
     r = __builtin_fma(-n, H2, r);
