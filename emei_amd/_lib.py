@@ -37,6 +37,10 @@ INTEGRATORS = {"euler": 0, "semi_implicit_euler": 1, "rk4": 2}
 NOISE_IID, NOISE_SHARED = 0, 1
 CONFIG_SIZE_V1 = 64
 MAX_STATE_DIM = 32
+MAX_ENV_PARAMS = 8
+# enum emei_env_param
+ENV_PARAMS = {"forward_reward_weight": 0, "ctrl_cost_weight": 1, "healthy_reward": 2, "terminate_when_unhealthy": 3,
+              "healthy_state_lo": 4, "healthy_state_hi": 5, "healthy_z_lo": 6, "healthy_z_hi": 7}
 
 
 class EmeiConfig(C.Structure):
@@ -59,6 +63,10 @@ class EmeiConfig(C.Structure):
         ("noise_layout", C.c_int32),
         ("init_sigma", C.c_float * MAX_STATE_DIM),
         ("obs_sigma", C.c_float * MAX_STATE_DIM),
+        # struct_size 400: constructor parameters of the reward / terminal functions
+        ("env_param_mask", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("env_params", C.c_double * MAX_ENV_PARAMS),
     ]
 
 
@@ -83,6 +91,8 @@ SYMBOLS = {
     "emei_episode_init_obs": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "emei_reward": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _dbl, _i32, _vp, _vp]),
     "emei_terminal": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp]),
+    "emei_reward_ex": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _dbl, _i32, _u32, _vp, _vp, _vp]),
+    "emei_terminal_ex": (C.c_int, [C.c_int, _i64, _vp, _u32, _vp, _vp, _vp]),
     "emei_next_obs": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _vp, _vp]),
     "emei_next_obs_ex": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _i32, _vp, _vp]),
 }
@@ -115,6 +125,17 @@ def lib():
             raise EmeiHipError(f"libemei_hip.so ABI {l.emei_abi_version()} != binding {ABI_VERSION}")
         _lib = l
     return _lib
+
+
+def pack_env_params(params):
+    """{name: value} (names of ENV_PARAMS) -> (mask, c_double[MAX_ENV_PARAMS]); None / {} -> the defaults."""
+    arr = (C.c_double * MAX_ENV_PARAMS)()
+    mask = 0
+    for k, v in (params or {}).items():
+        idx = ENV_PARAMS[k]
+        arr[idx] = float(v)
+        mask |= 1 << idx
+    return mask, arr
 
 
 def check(rc):

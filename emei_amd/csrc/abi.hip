@@ -75,6 +75,7 @@ extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, in
 // {sin, cos}(k * 2pi/256), k = 0..255, correctly rounded from long double, one copy per device.
 // Allocated on the first emei_create / stateless call for that device (never inside a hot launch
 // path of an existing handle).
+#include <cstddef>
 #include <mutex>
 namespace emei {
 const void* emei_trig_table(int device) {
@@ -165,9 +166,11 @@ static PendParams pend_params(int env_id, double dt, const float* init_sigma = n
 // ---------------------------------------------------------------------------------------------
 extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (!cfg || !out) return fail(EMEI_ERR_INVALID, "emei_create: null argument");
-    if (cfg->struct_size != sizeof(emei_config) && cfg->struct_size != EMEI_CONFIG_SIZE_V1)
-        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu (or the version-1 size %u)",
-                    cfg->struct_size, sizeof(emei_config), EMEI_CONFIG_SIZE_V1);
+    // older callers pass a shorter struct: every tail field has an all-zero default
+    const uint32_t size_v2a = (uint32_t)offsetof(emei_config, env_param_mask);  // 328: before env_params existed
+    if (cfg->struct_size != sizeof(emei_config) && cfg->struct_size != size_v2a && cfg->struct_size != EMEI_CONFIG_SIZE_V1)
+        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu (or the older sizes %u / %u)",
+                    cfg->struct_size, sizeof(emei_config), size_v2a, EMEI_CONFIG_SIZE_V1);
     emei_config c2;  // the caller's struct, widened to this library's layout
     memset(&c2, 0, sizeof(c2));
     memcpy(&c2, cfg, cfg->struct_size);
@@ -182,6 +185,11 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i)
         if (!(cfg->init_sigma[i] >= 0) || !(cfg->obs_sigma[i] >= 0))
             return fail(EMEI_ERR_INVALID, "emei_create: noise sigmas must be >= 0");
+    if (cfg->env_param_mask >> EMEI_MAX_ENV_PARAMS) return fail(EMEI_ERR_INVALID, "emei_create: env_param_mask=0x%x", cfg->env_param_mask);
+    if (cfg->env_param_mask != 0 && cfg->env_id != EMEI_HALFCHEETAH_RUNNING && cfg->env_id != EMEI_HOPPER_RUNNING)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_create: env_id %d takes no reward / health parameters", cfg->env_id);
+    if (cfg->env_id == EMEI_HALFCHEETAH_RUNNING && (cfg->env_param_mask >> 2))
+        return fail(EMEI_ERR_INVALID, "emei_create: HalfCheetahRunning has only the two reward weights");
     int od, ad, sd;
     if (emei_env_dims(cfg->env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
     if (cfg->n_envs <= 0 || cfg->n_envs > (int64_t)1 << 31)
@@ -297,6 +305,8 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     memcpy(L.noise.init, h->cfg.init_sigma, sizeof(L.noise.init));
     memcpy(L.noise.obs, h->cfg.obs_sigma, sizeof(L.noise.obs));
     L.noise.shared = h->cfg.noise_layout == EMEI_NOISE_SHARED;
+    L.env_params.mask = h->cfg.env_param_mask;
+    memcpy(L.env_params.v, h->cfg.env_params, sizeof(L.env_params.v));
     L.trig = h->trig;
     L.stream = (hipStream_t)stream;
     return L;
@@ -480,8 +490,19 @@ extern "C" EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
-                           double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {
+static int fill_env_params(int env_id, uint32_t mask, const double* params, EnvParams& ep, const char* fn) {
+    if (mask == 0) return EMEI_OK;
+    if (!params || (mask >> EMEI_MAX_ENV_PARAMS)) return fail(EMEI_ERR_INVALID, "%s: bad env_param_mask 0x%x / params", fn, mask);
+    if (env_id != EMEI_HALFCHEETAH_RUNNING && env_id != EMEI_HOPPER_RUNNING)
+        return fail(EMEI_ERR_UNSUPPORTED, "%s: env_id %d takes no reward / health parameters", fn, env_id);
+    ep.mask = mask;
+    memcpy(ep.v, params, sizeof(ep.v));
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                              double real_time_scale, int32_t freq_rate, uint32_t env_param_mask, const double* env_params,
+                              float* reward_out, void* stream) {
     if (n <= 0 || !obs || !reward_out) return fail(EMEI_ERR_INVALID, "emei_reward: bad argument");
     if (is_pend(env_id)) {
         PendLaunch L;
@@ -498,10 +519,11 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
         return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
     }
     if (is_body(env_id)) {
-        if (env_id == EMEI_HALFCHEETAH_RUNNING && (!pre_obs || !action))
-            return fail(EMEI_ERR_INVALID, "emei_reward: HalfCheetah needs pre_obs and action");
+        if ((env_id == EMEI_HALFCHEETAH_RUNNING || env_id == EMEI_HOPPER_RUNNING) && (!pre_obs || !action))
+            return fail(EMEI_ERR_INVALID, "emei_reward: this env's reward needs pre_obs and action");
         if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_reward: bad dt/freq_rate");
         BodyLaunch L;
+        if (int rc_ = fill_env_params(env_id, env_param_mask, env_params, L.env_params, "emei_reward")) return rc_;
         L.op = BODY_OP_REWARD;
         L.env_id = env_id;
         L.precision = EMEI_PRECISION_REF;
@@ -517,7 +539,13 @@ extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, con
     return fail(EMEI_ERR_INVALID, "emei_reward: unknown env_id %d", env_id);
 }
 
-extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream) {
+extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                           double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {
+    return emei_reward_ex(env_id, n, obs, pre_obs, action, real_time_scale, freq_rate, 0u, nullptr, reward_out, stream);
+}
+
+extern "C" EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t env_param_mask,
+                                const double* env_params, uint8_t* terminal_out, void* stream) {
     if (n <= 0 || !obs || !terminal_out) return fail(EMEI_ERR_INVALID, "emei_terminal: bad argument");
     if (is_pend(env_id)) {
         PendLaunch L;
@@ -535,6 +563,7 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
     }
     if (is_body(env_id)) {
         BodyLaunch L;
+        if (int rc_ = fill_env_params(env_id, env_param_mask, env_params, L.env_params, "emei_terminal")) return rc_;
         L.op = BODY_OP_TERMINAL;
         L.env_id = env_id;
         L.precision = EMEI_PRECISION_REF;
@@ -546,6 +575,10 @@ extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, u
         return rc == EMEI_OK ? rc : fail(rc, "emei_terminal: launch failed");
     }
     return fail(EMEI_ERR_INVALID, "emei_terminal: unknown env_id %d", env_id);
+}
+
+extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream) {
+    return emei_terminal_ex(env_id, n, obs, 0u, nullptr, terminal_out, stream);
 }
 
 extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,

@@ -4,7 +4,7 @@
 // the device reset and the LDS staging are generic and live here; a `Body` type supplies:
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
-//   struct Model; make_model(dt)                    // run-time constants, passed by value as a kernel argument
+//   struct Model; make_model(dt, env_params)        // run-time constants, passed by value as a kernel argument
 //   accel(q, v, ctrl, m, hd, qacc, trig)            // forward dynamics incl. soft constraints; `hd` = dt when
 //                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0;
 //                                                   // `trig` = the {sin,cos} table staged in LDS (emei_device.h)
@@ -26,6 +26,14 @@
 #include "emei_device.h"
 
 namespace emei {
+
+// constructor parameters of the reward / terminal functions that differ from the reference's defaults
+// (emei_hip.h: enum emei_env_param)
+struct EnvParams {
+    uint32_t mask = 0;
+    double v[EMEI_MAX_ENV_PARAMS] = {0};
+    double get(int k, double dflt) const { return (mask >> k) & 1u ? v[k] : dflt; }
+};
 
 // per-coordinate sigmas (state order: qpos then qvel) of the Gaussian init noise and of the
 // per-substep observation noise, float32 draws; host form (any body) and kernel-argument form
@@ -109,7 +117,10 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
         R qs[NV], vs[NV], dq[NV], dv[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) qs[i] = q[i], vs[i] = v[i], dq[i] = R(0), dv[i] = R(0);
-#pragma unroll 1
+        // Fully unrolled on purpose: with `#pragma unroll 1` this hipcc produced wrong front-leg accelerations for
+        // the cheetah instantiation (256 VGPR + 162 AGPR, 326 spilled SGPRs) — the same source is correct with
+        // every other body, and with the stages unrolled.  Caught by tests/test_gpu_integrators.py.
+#pragma unroll
         for (int st = 0; st < 4; ++st) {
             Body::accel(qs, vs, ctrl, m, R(0), acc, trig);
             const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);
@@ -151,6 +162,7 @@ struct BodyLaunch {
     double dt = 0.002;
     int32_t integrator = 0;
     NoiseSpec noise;
+    EnvParams env_params;
     const void* trig = nullptr;
     hipStream_t stream = nullptr;
 };
@@ -430,7 +442,7 @@ __global__ void __launch_bounds__(kBlock)
 template <class Body>
 static int launch_body(const BodyLaunch& L) {
     using R = typename Body::real;
-    const typename Body::Model m = Body::make_model(L.dt);
+    const typename Body::Model m = Body::make_model(L.dt, L.env_params);
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case BODY_OP_ROLLOUT: {

@@ -51,6 +51,7 @@ struct Model {
     double cK, cB, c_dmin, c_dmax, c_width;       // contact solref (refsafe'd for dt) / solimp
     double lK, lB, l_dmin, l_dmax, l_width;       // joint-limit solref / solimp
     double dt;
+    double w_forward, w_ctrl;  // reward weights (half_cheetah.py:23-24), run-time
 };
 
 template <typename R>
@@ -491,7 +492,11 @@ struct CheetahBody {
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;
-    static Model make_model(double dt) { return cheetah::cheetah_make_model(dt); }
+    static Model make_model(double dt, const EnvParams& ep) {
+        Model m = cheetah::cheetah_make_model(dt);
+        m.w_forward = ep.get(EMEI_PARAM_FORWARD_REWARD_WEIGHT, 1.0), m.w_ctrl = ep.get(EMEI_PARAM_CTRL_COST_WEIGHT, 0.1);
+        return m;
+    }
 
     __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
                                                  const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig) {
@@ -504,7 +509,7 @@ struct CheetahBody {
         R cost = R(0);
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);
-        rew = (s[0] - pre[0]) / ((R)m.dt * (R)freq_rate) - R(0.1) * cost;
+        rew = (R)m.w_forward * (s[0] - pre[0]) / ((R)m.dt * (R)freq_rate) - (R)m.w_ctrl * cost;
         bool fin = true;
 #pragma unroll
         for (int k = 0; k < NS; ++k) fin &= finite_r(s[k]), o[k] = (float)s[k];
@@ -522,7 +527,7 @@ struct CheetahBody {
         double cost = 0.0;
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
-        return ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - 0.1 * cost;
+        return m.w_forward * ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - m.w_ctrl * cost;
     }
     __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model&) {
         bool fin = true;

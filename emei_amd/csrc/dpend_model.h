@@ -69,7 +69,7 @@ struct DPendBody {
     static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;
-    static Model make_model(double dt) { return dpend::make_model(VARIANT >= 2, dt); }
+    static Model make_model(double dt, const EnvParams&) { return dpend::make_model(VARIANT >= 2, dt); }
 
     // q = (x, theta1, theta2), v = (v, omega1, omega2); no joint damping in this model, so `hd` is unused
     __device__ __forceinline__ static void accel(const R (&q)[3], const R (&v)[3], const R (&ctrl)[NA], const Model& m, R,

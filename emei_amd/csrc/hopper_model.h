@@ -41,6 +41,9 @@ struct Model {
     double cK, cB, c_dmin, c_dmax, c_width;  // contact solref (refsafe'd for dt) / solimp
     double lK, lB, l_dmin, l_dmax, l_width;  // joint-limit solref / solimp
     double dt;
+    // reward / health parameters (hopper.py:25-31), run-time
+    double w_forward, w_ctrl, healthy_reward, st_lo, st_hi, z_lo, z_hi;
+    int32_t terminate_when_unhealthy;
 };
 
 using cheetah::dot;
@@ -306,7 +309,15 @@ struct HopperBody {
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 12, NO = 12, NA = 3;
-    static Model make_model(double dt) { return hopper::make_model(dt); }
+    static Model make_model(double dt, const EnvParams& ep) {
+        Model m = hopper::make_model(dt);
+        m.w_forward = ep.get(EMEI_PARAM_FORWARD_REWARD_WEIGHT, 1.0), m.w_ctrl = ep.get(EMEI_PARAM_CTRL_COST_WEIGHT, 1e-3);
+        m.healthy_reward = ep.get(EMEI_PARAM_HEALTHY_REWARD, 1.0);
+        m.terminate_when_unhealthy = ep.get(EMEI_PARAM_TERMINATE_WHEN_UNHEALTHY, 1.0) != 0.0;
+        m.st_lo = ep.get(EMEI_PARAM_HEALTHY_STATE_LO, -100.0), m.st_hi = ep.get(EMEI_PARAM_HEALTHY_STATE_HI, 100.0);
+        m.z_lo = ep.get(EMEI_PARAM_HEALTHY_Z_LO, 0.7), m.z_hi = ep.get(EMEI_PARAM_HEALTHY_Z_HI, (double)INFINITY);
+        return m;
+    }
 
     __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
                                                  R (&qacc)[6], const TrigCtx& trig) {
@@ -315,22 +326,29 @@ struct HopperBody {
     // hopper.py:79-93 as executed: np.logical_and(healthy_state, healthy_z, healthy_angle) takes the
     // third argument as `out=`, so the angle range is never applied
     template <typename T>
-    __device__ __forceinline__ static bool is_healthy(const T* o) {
+    __device__ __forceinline__ static bool is_healthy(const T* o, const Model& m) {
         bool st = true;
 #pragma unroll
-        for (int k = 2; k < NO; ++k) st &= (T(-100) < o[k]) & (o[k] < T(100));
-        return st & (T(0.7) < o[1]) & (o[1] < T(INFINITY));
+        for (int k = 2; k < NO; ++k) st &= ((T)m.st_lo < o[k]) & (o[k] < (T)m.st_hi);
+        return st & ((T)m.z_lo < o[1]) & (o[1] < (T)m.z_hi);
     }
-    // obs = concat(qpos, qvel) (mujoco_env.py:153-155).  reward (hopper.py:95-102): healthy_reward is
-    // (is_healthy | terminate_when_unhealthy) * 1 = 1 for the default flag; + w_f (x' - x)/dt_env
-    // - 1e-3 sum a^2 (per env, step() semantics).  terminal (:104-106) = ~(is_healthy | True) = False.
+    // reward (hopper.py:95-102) = (is_healthy | terminate_when_unhealthy) * healthy_reward + w_f (x' - x)/dt_env
+    // - w_c sum a^2 (per env, step() semantics); terminal (:104-106) = ~(is_healthy | terminate_when_unhealthy):
+    // with the default flag (True) the reward term is constant and the env never terminates
+    template <typename T>
+    __device__ __forceinline__ static void reward_terminal(const T* o, T x_pre, T cost, const Model& m, int freq_rate, T& rew,
+                                                           bool& term) {
+        const bool ok = is_healthy(o, m) | (m.terminate_when_unhealthy != 0);
+        rew = (ok ? (T)m.healthy_reward : T(0)) + (T)m.w_forward * (o[0] - x_pre) / ((T)m.dt * (T)freq_rate) - (T)m.w_ctrl * cost;
+        term = !ok;
+    }
+    // obs = concat(qpos, qvel) (mujoco_env.py:153-155)
     __device__ __forceinline__ static void outputs(const R (&s)[NS], const R (&pre)[NS], const R (&ctrl)[NA], const Model& m,
                                                    int freq_rate, float (&o)[NO], R& rew, bool& term, const TrigCtx&) {
         R cost = R(0);
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost = fma_r(ctrl[k], ctrl[k], cost);
-        rew = R(1) + (s[0] - pre[0]) / ((R)m.dt * (R)freq_rate) - R(1e-3) * cost;
-        term = false;
+        reward_terminal(s, pre[0], cost, m, freq_rate, rew, term);
 #pragma unroll
         for (int k = 0; k < NS; ++k) o[k] = (float)s[k];
     }
@@ -341,12 +359,23 @@ struct HopperBody {
     }
     __device__ __forceinline__ static double batch_reward(const float* obs, const float* pre_obs, const float* act,
                                                           const Model& m, int freq_rate) {
-        double cost = 0.0;
+        double o[NO], cost = 0.0, rew;
+        bool term;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
-        return 1.0 + ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - 1e-3 * cost;
+        reward_terminal(o, (double)pre_obs[0], cost, m, freq_rate, rew, term);
+        return rew;
     }
-    __device__ __forceinline__ static bool batch_terminal(const float*, const Model&) { return false; }
+    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
+        double o[NO], rew;
+        bool term;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) o[k] = (double)obs[k];
+        reward_terminal(o, 0.0, 0.0, m, 1, rew, term);
+        return term;
+    }
 };
 
 }  // namespace emei

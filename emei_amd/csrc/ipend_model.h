@@ -65,7 +65,7 @@ struct InvPendBody {
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 4, NO = 4, NA = 1;
-    static Model make_model(double dt) { return ipend::make_model(VARIANT >= 2, dt); }
+    static Model make_model(double dt, const EnvParams&) { return ipend::make_model(VARIANT >= 2, dt); }
 
     // q = (x, theta), v = (xdot, omega); no joint damping in this model (`hd` unused)
     __device__ __forceinline__ static void accel(const R (&q)[2], const R (&v)[2], const R (&ctrl)[NA], const Model& m, R,

@@ -65,9 +65,10 @@ class Engine:
 
     def __init__(self, env_name, n_envs, freq_rate=1, real_time_scale=0.02, precision="ref", max_episode_steps=0,
                  device=None, seed=0, env_index_offset=0, init_noise=0.0, integrator="euler", obs_noise=0.0,
-                 noise_layout="iid"):
+                 noise_layout="iid", env_params=None):
         """init_noise / obs_noise: one sigma, a (qpos sigma, qvel sigma) pair, or one sigma per state coordinate
-        (qpos entries then qvel entries): the reduced forms of mujoco_env.py:218-227."""
+        (qpos entries then qvel entries): the reduced forms of mujoco_env.py:218-227.
+        env_params: {name: value} overriding reward / health constructor defaults (names: _lib.ENV_PARAMS)."""
         if env_name not in L.ENV_IDS:
             raise ValueError(f"unknown env {env_name!r}; known: {sorted(L.ENV_IDS)}")
         if integrator not in L.INTEGRATORS:
@@ -85,7 +86,8 @@ class Engine:
                            self.real_time_scale, int(max_episode_steps), self.device.index, int(seed),
                            int(env_index_offset), 0.0, L.INTEGRATORS[integrator],
                            {"iid": L.NOISE_IID, "shared": L.NOISE_SHARED}[noise_layout],
-                           sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)))
+                           sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)),
+                           *((lambda m, a: (m, 0, a))(*L.pack_env_params(env_params))))
         self._h = C.c_void_p()
         self._host_io = None
         with torch.cuda.device(self.device):
@@ -261,19 +263,22 @@ def _f32c(t, device):
     return None if t is None else torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
 
 
-def batch_reward(env_name, obs, pre_obs=None, action=None, real_time_scale=0.02, freq_rate=1):
+def batch_reward(env_name, obs, pre_obs=None, action=None, real_time_scale=0.02, freq_rate=1, env_params=None):
     obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     pre_obs, action = _f32c(pre_obs, obs.device), _f32c(action, obs.device)
     out = torch.empty(obs.shape[0], dtype=torch.float32, device=obs.device)
-    L.check(L.lib().emei_reward(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(pre_obs), _ptr(action),
-                                float(real_time_scale), int(freq_rate), _ptr(out), _stream()))
+    mask, arr = L.pack_env_params(env_params)
+    L.check(L.lib().emei_reward_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(pre_obs), _ptr(action),
+                                   float(real_time_scale), int(freq_rate), mask, C.cast(arr, C.c_void_p), _ptr(out), _stream()))
     return out
 
 
-def batch_terminal(env_name, obs):
+def batch_terminal(env_name, obs, env_params=None):
     obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     out = torch.empty(obs.shape[0], dtype=torch.uint8, device=obs.device)
-    L.check(L.lib().emei_terminal(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(out), _stream()))
+    mask, arr = L.pack_env_params(env_params)
+    L.check(L.lib().emei_terminal_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), mask, C.cast(arr, C.c_void_p), _ptr(out),
+                                     _stream()))
     return out.bool()
 
 

@@ -22,7 +22,7 @@ class HipEnv(EmeiEnv):
                  num_envs: int = 1, precision: str = "ref", device: Optional[int] = None,
                  max_episode_steps: Optional[int] = None, auto_reset: bool = False, init_noise=0.0,
                  env_index_offset: int = 0, obs_noise=0.0, noise_layout: Optional[str] = None,
-                 render_mode: Optional[str] = None):
+                 render_mode: Optional[str] = None, engine_env_params: Optional[dict] = None):
         if render_mode is not None:
             # base_control.py:15,21 / mujoco_env.py:33 accept "human" / "rgb_array"; pygame and the MuJoCo viewer
             # are outside the env-step path
@@ -37,6 +37,7 @@ class HipEnv(EmeiEnv):
         self.max_episode_steps = int(max_episode_steps or 0)
         self.auto_reset = bool(auto_reset)
         self._init_noise = init_noise
+        self._engine_env_params = dict(engine_env_params or {})  # non-default reward / health parameters (_lib.ENV_PARAMS)
         self._obs_noise = obs_noise
         # the reference only works for B = 1, where its row slicing shares one draw over all of qpos and
         # one over all of qvel (mujoco_env.py:243-244); the vectorised form draws per coordinate
@@ -83,7 +84,7 @@ class HipEnv(EmeiEnv):
                                   max_episode_steps=self.max_episode_steps, device=self.device_index,
                                   env_index_offset=self._env_index_offset, init_noise=self._init_noise,
                                   integrator=self.ENGINE_INTEGRATOR or "euler", obs_noise=self._obs_noise,
-                                  noise_layout=self._noise_layout)
+                                  noise_layout=self._noise_layout, env_params=self._engine_env_params)
         return self._engine
 
     def _host_init_state(self, batch_size) -> np.ndarray:
@@ -178,7 +179,7 @@ class HipEnv(EmeiEnv):
 
         o = self._to_dev(obs, torch.float32)
         r = E.batch_reward(self.ENGINE_NAME, o, self._to_dev(pre_obs, torch.float32), self._to_dev(action, torch.float32),
-                           self.real_time_scale, self.freq_rate)
+                           self.real_time_scale, self.freq_rate, self._engine_env_params)
         return self._like(r, obs, np.float64)
 
     def get_batch_terminal(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
@@ -186,7 +187,7 @@ class HipEnv(EmeiEnv):
 
         from .. import engine as E
 
-        t = E.batch_terminal(self.ENGINE_NAME, self._to_dev(obs, torch.float32))
+        t = E.batch_terminal(self.ENGINE_NAME, self._to_dev(obs, torch.float32), self._engine_env_params)
         return self._like(t, obs, np.bool_)
 
     def get_batch_next_obs(self, obs, pre_obs=None, action=None, state=None, pre_state=None):

@@ -5,7 +5,7 @@ stepped with RK4 by default like the reference (:22); parity with libmujoco is u
 Reference behaviour kept as it EXECUTES: ``np.logical_and(healthy_state, healthy_z,
 healthy_angle)`` passes the angle test as ``out=`` so it never applies (:91); with the default
 ``terminate_when_unhealthy=True`` the healthy reward is always 1 (:99) and ``terminal`` is always False
-(:104-106)."""
+(:104-106); ``terminate_when_unhealthy=False`` is what makes the env terminate when unhealthy."""
 import numpy as np
 
 from .. import spaces
@@ -22,10 +22,13 @@ class HopperRunningEnv(MujocoHipEnv):
                  ctrl_cost_weight: float = 1e-3, healthy_reward: float = 1.0, terminate_when_unhealthy: bool = True,
                  healthy_state_range=(-100.0, 100.0), healthy_z_range=(0.7, float("inf")),
                  healthy_angle_range=(-0.2, 0.2), **kwargs):
-        defaults = (1.0, 1e-3, 1.0, True, (-100.0, 100.0), (0.7, float("inf")))
-        if (forward_reward_weight, ctrl_cost_weight, healthy_reward, terminate_when_unhealthy, tuple(healthy_state_range),
-                tuple(healthy_z_range)) != defaults:
-            raise NotImplementedError("only the default reward / health parameters (hopper.py:25-30) are compiled in")
+        given = dict(forward_reward_weight=forward_reward_weight, ctrl_cost_weight=ctrl_cost_weight,
+                     healthy_reward=healthy_reward, terminate_when_unhealthy=float(bool(terminate_when_unhealthy)),
+                     healthy_state_lo=healthy_state_range[0], healthy_state_hi=healthy_state_range[1],
+                     healthy_z_lo=healthy_z_range[0], healthy_z_hi=healthy_z_range[1])
+        defaults = dict(forward_reward_weight=1.0, ctrl_cost_weight=1e-3, healthy_reward=1.0, terminate_when_unhealthy=1.0,
+                        healthy_state_lo=-100.0, healthy_state_hi=100.0, healthy_z_lo=0.7, healthy_z_hi=float("inf"))
+        params = {k: float(v) for k, v in given.items() if float(v) != defaults[k]}  # hopper.py:25-30
         self._forward_reward_weight = forward_reward_weight
         self._ctrl_cost_weight = ctrl_cost_weight
         self._healthy_reward = healthy_reward
@@ -34,7 +37,8 @@ class HopperRunningEnv(MujocoHipEnv):
         self._healthy_z_range = healthy_z_range
         self._healthy_angle_range = healthy_angle_range  # accepted and, like the reference, never applied (:91)
         super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator,
-                         init_noise_params=init_noise_params, obs_noise_params=obs_noise_params, **kwargs)
+                         init_noise_params=init_noise_params, obs_noise_params=obs_noise_params,
+                         engine_env_params=params, **kwargs)
         self.observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=(12,), dtype=np.float64)
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(3,), dtype=np.float32)  # ctrlrange, xml:37-39
 

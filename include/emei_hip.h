@@ -85,6 +85,22 @@ enum emei_action_dtype { EMEI_ACT_U8 = 0, EMEI_ACT_I32 = 1, EMEI_ACT_I64 = 2, EM
 #define EMEI_ERR_STATE -4       /* call order: e.g. step before reset (base_control.py:67) */
 
 #define EMEI_MAX_STATE_DIM 32
+#define EMEI_MAX_ENV_PARAMS 8
+
+/* Indices into env_params.  HalfCheetahRunning (half_cheetah.py:23-24) uses 0-1; HopperRunning
+ * (hopper.py:25-31) uses 0-7.  Defaults: cheetah 1.0, 0.1; hopper 1.0, 1e-3, 1.0, 1 (True), -100, 100,
+ * 0.7, +inf.  The Hopper's healthy_angle_range is accepted by the Python class and, as in the reference
+ * (np.logical_and's third argument is `out=`, hopper.py:91), never applied. */
+enum emei_env_param {
+    EMEI_PARAM_FORWARD_REWARD_WEIGHT = 0,
+    EMEI_PARAM_CTRL_COST_WEIGHT = 1,
+    EMEI_PARAM_HEALTHY_REWARD = 2,
+    EMEI_PARAM_TERMINATE_WHEN_UNHEALTHY = 3, /* 0 / 1 */
+    EMEI_PARAM_HEALTHY_STATE_LO = 4,
+    EMEI_PARAM_HEALTHY_STATE_HI = 5,
+    EMEI_PARAM_HEALTHY_Z_LO = 6,
+    EMEI_PARAM_HEALTHY_Z_HI = 7
+};
 
 typedef struct emei_env emei_env; /* opaque */
 
@@ -112,6 +128,11 @@ typedef struct emei_config {
      * of joint 0 (index 0 and state_dim/2) are used, as in the reference. */
     float init_sigma[EMEI_MAX_STATE_DIM];
     float obs_sigma[EMEI_MAX_STATE_DIM];
+    /* -- from struct_size 400: constructor parameters of the reward / terminal functions.  Bit k of
+     *    env_param_mask set = env_params[k] overrides the reference's default (enum emei_env_param). ---- */
+    uint32_t env_param_mask;
+    uint32_t reserved0;
+    double env_params[EMEI_MAX_ENV_PARAMS];
 } emei_config;
 #define EMEI_CONFIG_SIZE_V1 64u
 
@@ -187,6 +208,13 @@ EMEI_API int emei_episode_init_obs(emei_env* h, int64_t count, const int64_t* en
 EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
                 double real_time_scale, int32_t freq_rate, float* reward_out, void* stream);
 EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream);
+
+/* The same with constructor parameters (enum emei_env_param; mask 0 = the defaults above). */
+EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                   double real_time_scale, int32_t freq_rate, uint32_t env_param_mask, const double* env_params,
+                   float* reward_out, void* stream);
+EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t env_param_mask, const double* env_params,
+                     uint8_t* terminal_out, void* stream);
 
 /* EmeiEnv.get_batch_next_obs (core.py:190-193; abstract in the reference, no env implements it):
  * one step from caller-supplied float32 observations without touching any handle state.

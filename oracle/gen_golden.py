@@ -379,6 +379,8 @@ def gen_mujoco_firstparty(ref, out):
         data["cheetah_reward_B1"] = r1
         data["cheetah_reward_batchquirk"] = hc.HalfCheetahRunningEnv.get_batch_reward(f, o, po, a)
         data["cheetah_terminal"] = hc.HalfCheetahRunningEnv.get_batch_terminal(f, o)
+        fw = NS(_forward_reward_weight=2.5, _ctrl_cost_weight=0.03, dt=0.002 * 4)  # non-default weights (half_cheetah.py:23-24)
+        data["cheetah_reward_B1_w2p5_c0p03"] = np.stack([hc.HalfCheetahRunningEnv.get_batch_reward(fw, o[i : i + 1], po[i : i + 1], a[i : i + 1])[0, 0] for i in range(Bc)])
 
     # env_params_name string KAT (core.py:56-58; test/test_core.py:9-14)
     names = []
@@ -461,6 +463,16 @@ def gen_hopper_firstparty(ref, out):
         # the reference's own test inputs (test_hopper.py:9-13)
         data["hopper_is_healthy_ones"] = np.asarray(cls.is_healthy(f, np.ones([128, 12])))
         data["hopper_is_healthy_101"] = np.asarray(cls.is_healthy(f, np.ones([128, 12]) * 101))
+    # the same functions with NON-default constructor parameters (hopper.py:25-30): terminate_when_unhealthy = False is
+    # what makes the env terminate; custom weights, healthy reward and ranges
+    f2 = NS(_forward_reward_weight=2.0, _ctrl_cost_weight=5e-3, _healthy_reward=0.5, _terminate_when_unhealthy=False,
+            _healthy_state_range=(-50.0, 60.0), _healthy_z_range=(0.8, 1.5), _healthy_angle_range=(-0.2, 0.2), dt=0.002 * 4)
+    f2.is_healthy = lambda o_: cls.is_healthy(f2, o_)
+    with np.errstate(all="ignore"):
+        data["hopper_custom_params"] = np.array([2.0, 5e-3, 0.5, 0.0, -50.0, 60.0, 0.8, 1.5])
+        data["hopper_custom_is_healthy"] = np.asarray(cls.is_healthy(f2, o.copy()))
+        data["hopper_custom_reward_B1"] = np.stack([cls.get_batch_reward(f2, o[i : i + 1].copy(), po[i : i + 1], a[i : i + 1])[0, 0] for i in range(B)])
+        data["hopper_custom_terminal"] = np.asarray(cls.get_batch_terminal(f2, o.copy()))
     # additive_gaussian_noise for B = 1: float, tuple and dict parameters
     fm = NS(model=NS(jnt_type=[2, 2, 3, 3, 3, 3]))
     q0 = np.array([[0.0, 1.25, 0.0, 0.0, 0.0, 0.0]])

@@ -243,25 +243,41 @@ def ip_wrap(theta):
 
 
 # --------------------------------------------------------------------------- HalfCheetah-style body (C)
-def cheetah_step(state, action, freq_rate=4, dt=0.002, opt=None):
+ENV_PARAM_ORDER = ("forward_reward_weight", "ctrl_cost_weight", "healthy_reward", "terminate_when_unhealthy",
+                   "healthy_state_lo", "healthy_state_hi", "healthy_z_lo", "healthy_z_hi")
+CHEETAH_DEFAULTS = dict(forward_reward_weight=1.0, ctrl_cost_weight=0.1)
+HOPPER_DEFAULTS = dict(forward_reward_weight=1.0, ctrl_cost_weight=1e-3, healthy_reward=1.0, terminate_when_unhealthy=1.0,
+                       healthy_state_lo=-100.0, healthy_state_hi=100.0, healthy_z_lo=0.7, healthy_z_hi=float("inf"))
+
+
+def _params(defaults, overrides):
+    """Full parameter vector (order of emei_hip.h's enum emei_env_param) from defaults + {name: value} overrides."""
+    d = dict(defaults)
+    d.update(overrides or {})
+    return np.array([float(d.get(k, 0.0)) for k in ENV_PARAM_ORDER])
+
+
+def cheetah_step(state, action, freq_rate=4, dt=0.002, opt=None, params=None):
     """state [n,18] = (qpos, qvel) float64 (copied), action [n,6] -> (next_state, reward, terminal)."""
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 18)
     n = st.shape[0]
     act = np.ascontiguousarray(action, dtype=np.float64).reshape(n, 6)
     rew = np.empty(n)
     term = np.empty(n, np.uint8)
-    lib().cheetah_oracle_step_ex(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
-                                 _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt))
+    P = _params(CHEETAH_DEFAULTS, params)
+    lib().cheetah_oracle_step_p(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
+                                _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt), _p(P, C.c_double))
     return st, rew, term.astype(bool)
 
 
-def cheetah_reward(obs, pre_obs, act, dt_env):
+def cheetah_reward(obs, pre_obs, act, dt_env, params=None):
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 18)
     pre = np.ascontiguousarray(pre_obs, np.float64).reshape(-1, 18)
     a = np.ascontiguousarray(act, np.float64).reshape(-1, 6)
     out = np.empty(len(obs))
-    lib().cheetah_oracle_reward(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
-                                C.c_double(dt_env), _p(out, C.c_double))
+    P = _params(CHEETAH_DEFAULTS, params)
+    lib().cheetah_oracle_reward_p(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
+                                  C.c_double(dt_env), _p(P, C.c_double), _p(out, C.c_double))
     return out
 
 
@@ -318,7 +334,7 @@ def planar_bodies(body, q):
 
 
 # --------------------------------------------------------------------------- Hopper (C)
-def hopper_step(state, action, freq_rate=4, dt=0.002, opt=None):
+def hopper_step(state, action, freq_rate=4, dt=0.002, opt=None, params=None):
     """state [n,12] = (qpos, qvel) float64 (copied), action [n,3] -> (next_state, reward, terminal).
     The reference's default integrator for this env is "rk4" (hopper.py:22): pass opt=opts("rk4")."""
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 12)
@@ -326,26 +342,35 @@ def hopper_step(state, action, freq_rate=4, dt=0.002, opt=None):
     act = np.ascontiguousarray(action, dtype=np.float64).reshape(n, 3)
     rew = np.empty(n)
     term = np.empty(n, np.uint8)
-    lib().hopper_oracle_step_ex(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
-                                _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt))
+    P = _params(HOPPER_DEFAULTS, params)
+    lib().hopper_oracle_step_p(C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double),
+                               _p(act, C.c_double), _p(rew, C.c_double), _p(term, C.c_uint8), _o(opt), _p(P, C.c_double))
     return st, rew, term.astype(bool)
 
 
-def hopper_reward(obs, pre_obs, act, dt_env):
+def hopper_reward(obs, pre_obs, act, dt_env, params=None):
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 12)
     pre = np.ascontiguousarray(pre_obs, np.float64).reshape(-1, 12)
     a = np.ascontiguousarray(act, np.float64).reshape(-1, 3)
     out = np.empty(len(obs))
-    lib().hopper_oracle_reward(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
-                               C.c_double(dt_env), _p(out, C.c_double))
+    P = _params(HOPPER_DEFAULTS, params)
+    lib().hopper_oracle_reward_p(C.c_int64(len(obs)), _p(obs, C.c_double), _p(pre, C.c_double), _p(a, C.c_double),
+                                 C.c_double(dt_env), _p(P, C.c_double), _p(out, C.c_double))
     return out
 
 
-def hopper_is_healthy(obs):
+def hopper_is_healthy(obs, params=None):
+    return hopper_healthy_terminal(obs, params)[0]
+
+
+def hopper_healthy_terminal(obs, params=None):
+    """(is_healthy, terminal) of hopper.py:79-93,104-106 as executed, for the given constructor parameters."""
     obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 12)
-    out = np.empty(len(obs), np.uint8)
-    lib().hopper_oracle_is_healthy(C.c_int64(len(obs)), _p(obs, C.c_double), _p(out, C.c_uint8))
-    return out.astype(bool)
+    healthy, term = np.empty(len(obs), np.uint8), np.empty(len(obs), np.uint8)
+    P = _params(HOPPER_DEFAULTS, params)
+    lib().hopper_oracle_is_healthy_p(C.c_int64(len(obs)), _p(obs, C.c_double), _p(P, C.c_double), _p(healthy, C.c_uint8),
+                                     _p(term, C.c_uint8))
+    return healthy.astype(bool), term.astype(bool)
 
 
 # --------------------------------------------------------------------------- InvertedDoublePendulum (C)

@@ -364,11 +364,17 @@ static void planar_accel(const void* ctx, double dt, double hd, const double* q,
     }
 }
 
+/* Constructor parameters of the reward / terminal functions in the order of emei_hip.h's enum emei_env_param:
+ * forward_reward_weight, ctrl_cost_weight, healthy_reward, terminate_when_unhealthy, healthy_state lo / hi,
+ * healthy_z lo / hi.  NULL = the reference's defaults. */
+static const double kCheetahDefaults[8] = {1.0, 0.1, 0, 0, 0, 0, 0, 0};                 /* half_cheetah.py:23-24 */
+static const double kHopperDefaults[8] = {1.0, 1e-3, 1.0, 1.0, -100.0, 100.0, 0.7, INFINITY}; /* hopper.py:25-30 */
+
 /* half_cheetah.py:59-63 with step() semantics (one env per call) and :65-67 */
-static double cheetah_reward(const double* obs, const double* pre_obs, const double* act, double dt_env) {
+static double cheetah_reward(const double* obs, const double* pre_obs, const double* act, double dt_env, const double* P) {
     double cost = 0;
     for (int a = 0; a < 6; ++a) cost += act[a] * act[a];
-    return 1.0 * (obs[0] - pre_obs[0]) / dt_env - 0.1 * cost;
+    return P[0] * (obs[0] - pre_obs[0]) / dt_env - P[1] * cost;
 }
 static uint8_t cheetah_terminal(const double* obs) {
     int fin = 1;
@@ -377,8 +383,9 @@ static uint8_t cheetah_terminal(const double* obs) {
 }
 
 /* mujoco_env.py:157-167 for a batch: state [n,18] = (qpos, qvel) in/out, action [n,6] */
-EXPORT void cheetah_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
-                                   uint8_t* terminal, const oracle_opts_t* opts) {
+EXPORT void cheetah_oracle_step_p(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                  uint8_t* terminal, const oracle_opts_t* opts, const double* params) {
+    const double* P = params ? params : kCheetahDefaults;
     planar_model_t m;
     cheetah_oracle_model(&m);
 #pragma omp parallel for schedule(static)
@@ -387,17 +394,26 @@ EXPORT void cheetah_oracle_step_ex(int64_t n, int freq_rate, double dt, double* 
         double pre[18];
         memcpy(pre, s, sizeof(pre));
         oracle_env_step(planar_accel, &m, 9, freq_rate, dt, opts, i, s, s + 9, action + 6 * i);
-        reward[i] = cheetah_reward(s, pre, action + 6 * i, dt * freq_rate);
+        reward[i] = cheetah_reward(s, pre, action + 6 * i, dt * freq_rate, P);
         terminal[i] = cheetah_terminal(s);
     }
 }
+EXPORT void cheetah_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                   uint8_t* terminal, const oracle_opts_t* opts) {
+    cheetah_oracle_step_p(n, freq_rate, dt, state, action, reward, terminal, opts, NULL);
+}
 EXPORT void cheetah_oracle_step(int64_t n, int freq_rate, double dt, double* state, const double* action,
                                 double* reward, uint8_t* terminal) {
-    cheetah_oracle_step_ex(n, freq_rate, dt, state, action, reward, terminal, NULL);
+    cheetah_oracle_step_p(n, freq_rate, dt, state, action, reward, terminal, NULL, NULL);
 }
 
+EXPORT void cheetah_oracle_reward_p(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env,
+                                    const double* params, double* out) {
+    const double* P = params ? params : kCheetahDefaults;
+    for (int64_t i = 0; i < n; ++i) out[i] = cheetah_reward(obs + 18 * i, pre_obs + 18 * i, act + 6 * i, dt_env, P);
+}
 EXPORT void cheetah_oracle_reward(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env, double* out) {
-    for (int64_t i = 0; i < n; ++i) out[i] = cheetah_reward(obs + 18 * i, pre_obs + 18 * i, act + 6 * i, dt_env);
+    cheetah_oracle_reward_p(n, obs, pre_obs, act, dt_env, NULL, out);
 }
 EXPORT void cheetah_oracle_terminal(int64_t n, const double* obs, uint8_t* out) {
     for (int64_t i = 0; i < n; ++i) out[i] = cheetah_terminal(obs + 18 * i);
@@ -406,21 +422,25 @@ EXPORT void cheetah_oracle_terminal(int64_t n, const double* obs, uint8_t* out) 
 /* ---------------------------------------------------------------------------------------------
  * Hopper (hopper.py).  is_healthy (:79-93) as the reference EXECUTES it: np.logical_and(healthy_state,
  * healthy_z, healthy_angle) passes healthy_angle as `out=`, so the result is healthy_state & healthy_z
- * and the angle range never matters.  terminal = ~(is_healthy | terminate_when_unhealthy) (:104-106)
- * is False for the default terminate_when_unhealthy = True; the healthy reward
- * (is_healthy | True) * 1.0 (:99) is always 1.  Per-env control cost (step() semantics). */
-static int hopper_is_healthy(const double* obs) {
+ * and the angle range never matters.  healthy reward = (is_healthy | terminate_when_unhealthy) *
+ * healthy_reward (:99); terminal = ~(is_healthy | terminate_when_unhealthy) (:104-106): with the default
+ * flag (True) the reward term is constant and the env never terminates.  Per-env control cost (step()). */
+static int hopper_is_healthy(const double* obs, const double* P) {
     int st = 1;
-    for (int i = 2; i < 12; ++i) st &= (-100.0 < obs[i]) && (obs[i] < 100.0);
-    return st && (0.7 < obs[1]) && (obs[1] < INFINITY);
+    for (int i = 2; i < 12; ++i) st &= (P[4] < obs[i]) && (obs[i] < P[5]);
+    return st && (P[6] < obs[1]) && (obs[1] < P[7]);
 }
-static double hopper_reward(const double* obs, const double* pre_obs, const double* act, double dt_env) {
+static double hopper_reward(const double* obs, const double* pre_obs, const double* act, double dt_env, const double* P) {
     double cost = 0;
     for (int a = 0; a < 3; ++a) cost += act[a] * act[a];
-    return 1.0 + 1.0 * (obs[0] - pre_obs[0]) / dt_env - 1e-3 * cost;
+    int ok = hopper_is_healthy(obs, P) || (P[3] != 0.0);
+    return (ok ? P[2] : 0.0) + P[0] * (obs[0] - pre_obs[0]) / dt_env - P[1] * cost;
 }
-EXPORT void hopper_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
-                                  uint8_t* terminal, const oracle_opts_t* opts) {
+static uint8_t hopper_terminal(const double* obs, const double* P) { return (uint8_t)!(hopper_is_healthy(obs, P) || (P[3] != 0.0)); }
+
+EXPORT void hopper_oracle_step_p(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                 uint8_t* terminal, const oracle_opts_t* opts, const double* params) {
+    const double* P = params ? params : kHopperDefaults;
     planar_model_t m;
     hopper_oracle_model(&m);
 #pragma omp parallel for schedule(static)
@@ -429,15 +449,31 @@ EXPORT void hopper_oracle_step_ex(int64_t n, int freq_rate, double dt, double* s
         double pre[12];
         memcpy(pre, s, sizeof(pre));
         oracle_env_step(planar_accel, &m, 6, freq_rate, dt, opts, i, s, s + 6, action + 3 * i);
-        reward[i] = hopper_reward(s, pre, action + 3 * i, dt * freq_rate);
-        terminal[i] = 0;
+        reward[i] = hopper_reward(s, pre, action + 3 * i, dt * freq_rate, P);
+        terminal[i] = hopper_terminal(s, P);
     }
 }
+EXPORT void hopper_oracle_step_ex(int64_t n, int freq_rate, double dt, double* state, const double* action, double* reward,
+                                  uint8_t* terminal, const oracle_opts_t* opts) {
+    hopper_oracle_step_p(n, freq_rate, dt, state, action, reward, terminal, opts, NULL);
+}
+EXPORT void hopper_oracle_reward_p(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env,
+                                   const double* params, double* out) {
+    const double* P = params ? params : kHopperDefaults;
+    for (int64_t i = 0; i < n; ++i) out[i] = hopper_reward(obs + 12 * i, pre_obs + 12 * i, act + 3 * i, dt_env, P);
+}
 EXPORT void hopper_oracle_reward(int64_t n, const double* obs, const double* pre_obs, const double* act, double dt_env, double* out) {
-    for (int64_t i = 0; i < n; ++i) out[i] = hopper_reward(obs + 12 * i, pre_obs + 12 * i, act + 3 * i, dt_env);
+    hopper_oracle_reward_p(n, obs, pre_obs, act, dt_env, NULL, out);
+}
+EXPORT void hopper_oracle_is_healthy_p(int64_t n, const double* obs, const double* params, uint8_t* healthy, uint8_t* terminal) {
+    const double* P = params ? params : kHopperDefaults;
+    for (int64_t i = 0; i < n; ++i) {
+        if (healthy) healthy[i] = (uint8_t)hopper_is_healthy(obs + 12 * i, P);
+        if (terminal) terminal[i] = hopper_terminal(obs + 12 * i, P);
+    }
 }
 EXPORT void hopper_oracle_is_healthy(int64_t n, const double* obs, uint8_t* out) {
-    for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)hopper_is_healthy(obs + 12 * i);
+    hopper_oracle_is_healthy_p(n, obs, NULL, out, NULL);
 }
 
 /* diagnostics for the tests: mass matrix [nv,nv], bias and total mechanical energy at (q, v); body 0 = cheetah, 1 = hopper */

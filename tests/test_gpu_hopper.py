@@ -139,3 +139,45 @@ def test_auto_reset_truncation_and_dataset():
     # observations after a reset are the device init obs: z back near 1.25
     o = d["observations"].reshape(64, 12, 12)
     assert float((o[:, 5, 1] - 1.25).abs().max()) < 0.03 and float((o[:, 10, 1] - 1.25).abs().max()) < 0.03
+
+
+def test_constructor_parameters_on_the_device(hopper_golden, mujoco_golden):
+    """Non-default reward / health parameters (hopper.py:25-30, half_cheetah.py:23-24) travel as emei_config.env_params:
+    stateless functions vs the golden vectors, fused step vs the oracle, and a Hopper that really terminates."""
+    import emei_amd
+    from oracle import oracle as O
+
+    g = hopper_golden
+    o, po, ac = g["hopper_obs"], g["hopper_pre_obs"], g["hopper_action"]
+    env = emei_amd.HopperRunningEnv(forward_reward_weight=2.0, ctrl_cost_weight=5e-3, healthy_reward=0.5, terminate_when_unhealthy=False,
+                                    healthy_state_range=(-50.0, 60.0), healthy_z_range=(0.8, 1.5), num_envs=512, auto_reset=True)
+    ok = np.isfinite(o).all(axis=1) & (np.abs(o[:, 1] - 0.8) > 1e-4) & (np.abs(o[:, 1] - 1.5) > 1e-4)  # float32 inputs: keep off the thresholds
+    assert np.array_equal(env.get_batch_terminal(o[ok]), g["hopper_custom_terminal"][ok])
+    assert rel_err(env.get_batch_reward(o[ok], po[ok], ac[ok])[:, 0], g["hopper_custom_reward_B1"][ok]) <= 5e-4  # float32 dx / 0.008 x 2
+    prm = dict(zip(O.ENV_PARAM_ORDER, g["hopper_custom_params"]))
+    rng = np.random.default_rng(6)
+    q = rng.normal(0, 0.1, (512, 6))
+    q[:, 1] = rng.uniform(0.5, 1.7, 512)  # around both z thresholds
+    s0 = np.concatenate([q, rng.normal(0, 1, (512, 6))], axis=1)
+    act = rng.uniform(-1, 1, (512, 3)).astype(np.float32)
+    env.engine.set_state(s0)
+    obs, rew, done = env.engine.step(torch.as_tensor(act, device="cuda"), auto_reset=False)
+    o_st, o_rew, o_term = O.hopper_step(s0, act.astype(np.float64), 4, 0.002, O.opts("rk4"), prm)
+    near = (np.abs(o_st[:, 1] - 0.8) < 1e-9) | (np.abs(o_st[:, 1] - 1.5) < 1e-9)
+    assert rel_err(obs.cpu().numpy(), o_st) <= 1e-5 and rel_err(rew.cpu().numpy()[~near], o_rew[~near]) <= 2e-5
+    assert np.array_equal((done.cpu().numpy() & 1).astype(bool)[~near], o_term[~near]) and o_term.any() and not o_term.all()
+    # episodes now end: a rollout with auto-reset counts terminal steps and keeps z inside the range right after resets
+    env.reset(seed=1, options={"device_rng": True})
+    acts = (torch.rand((60, 512, 3), device="cuda") * 2 - 1).float()
+    _, _, term, trunc = env.rollout(acts)
+    assert bool(term.any()) and not bool(trunc.any())
+    # cheetah weights
+    m = mujoco_golden
+    ch = emei_amd.HalfCheetahRunningEnv(forward_reward_weight=2.5, ctrl_cost_weight=0.03)
+    okc = np.isfinite(m["cheetah_obs"]).all(axis=1)
+    r = ch.get_batch_reward(m["cheetah_obs"][okc], m["cheetah_pre_obs"][okc], m["cheetah_action"][okc])
+    assert rel_err(r[:, 0], m["cheetah_reward_B1_w2p5_c0p03"][okc]) <= 5e-4
+    with pytest.raises(NotImplementedError):  # envs without such parameters refuse them
+        from emei_amd.engine import Engine
+
+        Engine("CartPoleSwingUp", 64, env_params={"forward_reward_weight": 2.0})

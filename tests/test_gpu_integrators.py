@@ -227,3 +227,28 @@ def test_batch_next_obs_env_surface_and_unsupported():
     assert nxt.shape == (8, 12) and nxt.dtype == np.float64 and np.all(nxt[:, 1] < 1.25) and np.allclose(nxt, nxt[:1])
     with pytest.raises(NotImplementedError):  # the double pendulum's observation wrap is not invertible
         E.batch_next_obs("BoundaryInvertedDoublePendulumSwingUp", torch.zeros((4, 6), device="cuda"), torch.zeros((4, 1), device="cuda"))
+
+
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+@pytest.mark.parametrize("body", ["ip", "dpend", "cheetah", "hopper"])
+def test_integrators_f32_mode_tracks_oracle(body, integrator):
+    """Every (body, integrator) instantiation of the float32 kernels against the float64 oracle, on benign states
+    (no deep contact / far-beyond-limit rows, whose stiff terms amplify float32 rounding): a gross check that each
+    template instantiation computes the same physics."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(23)
+    n = 320
+    name, s0, act, ostep, dt = _case(body, rng, n)
+    if body in ("cheetah", "hopper"):
+        nv = s0.shape[1] // 2
+        s0[:, 1] += 1.0  # in flight: no contacts
+        s0[:, 3:nv] = np.clip(s0[:, 3:nv], -0.3, 0.3) if body == "cheetah" else -np.abs(np.clip(s0[:, 3:nv], -0.3, 0.3)) * [1, 1, 0.5]
+    else:
+        s0[:, 0] = np.clip(s0[:, 0], -1.5, 1.5)
+    act32 = act.astype(np.float32)
+    eng = _engine(name, n, freq_rate=2, real_time_scale=dt, integrator=integrator, precision="f32")
+    eng.set_state(s0)
+    obs, rew, done = eng.step(torch.as_tensor(act32, device=eng.device))
+    o_st, o_obs, o_rew, o_term = ostep(s0.astype(np.float32).astype(np.float64), act32.astype(np.float64), 2, dt, O.opts(integrator))
+    assert rel_err(obs.cpu().numpy(), o_obs) <= 2e-3, (body, integrator)

@@ -169,3 +169,23 @@ def test_obs_noise_stream_and_layouts():
         assert np.array_equal(again, noisy)
     many = np.stack([O.body_init(3, e, 0, 6, 0.1, 0.2) for e in range(4000)])
     assert many[:, :6].std() == pytest.approx(0.1, rel=0.03) and many[:, 6:].std() == pytest.approx(0.2, rel=0.03)
+
+
+def test_custom_constructor_parameters_vs_golden(hopper_golden, mujoco_golden):
+    """hopper.py:25-30 / half_cheetah.py:23-24 with non-default values: terminate_when_unhealthy = False is what
+    makes the Hopper terminate; weights, healthy reward and ranges all enter."""
+    g = hopper_golden
+    o, po, a = g["hopper_obs"], g["hopper_pre_obs"], g["hopper_action"]
+    names = O.ENV_PARAM_ORDER
+    prm = dict(zip(names, g["hopper_custom_params"]))
+    healthy, term = O.hopper_healthy_terminal(o, prm)
+    assert np.array_equal(healthy, g["hopper_custom_is_healthy"]) and np.array_equal(term[:, None], g["hopper_custom_terminal"])
+    assert term.any() and not term.all() and np.array_equal(term, ~healthy)
+    with np.errstate(all="ignore"):
+        r = O.hopper_reward(o, po, a, 0.008, prm)
+    assert rel_err(r, g["hopper_custom_reward_B1"], floor=1e-300) <= 1e-12
+    m = mujoco_golden
+    with np.errstate(all="ignore"):
+        rc = O.cheetah_reward(m["cheetah_obs"], m["cheetah_pre_obs"], m["cheetah_action"], 0.008,
+                              dict(forward_reward_weight=2.5, ctrl_cost_weight=0.03))
+    assert rel_err(rc, m["cheetah_reward_B1_w2p5_c0p03"], floor=1e-300) <= 1e-12
