@@ -15,6 +15,7 @@
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
 //   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
+//   kUnrollRK4                                      // RK4 stages as straight-line code (see body_substep)
 //
 // Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
 // observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
@@ -117,11 +118,12 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
         R qs[NV], vs[NV], dq[NV], dv[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) qs[i] = q[i], vs[i] = v[i], dq[i] = R(0), dv[i] = R(0);
-        // Fully unrolled on purpose: with `#pragma unroll 1` this hipcc produced wrong front-leg accelerations for
-        // the cheetah instantiation (256 VGPR + 162 AGPR, 326 spilled SGPRs) — the same source is correct with
-        // every other body, and with the stages unrolled.  Caught by tests/test_gpu_integrators.py.
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        // Body::kUnrollRK4: the four stages as straight-line code or as a rolled loop.  The cheetah MUST unroll:
+        // with `#pragma unroll 1` this hipcc produced wrong front-leg accelerations for that instantiation (256 VGPR
+        // + 162 AGPR, 326 spilled SGPRs) while the same source is correct for every other body and for the unrolled
+        // form (caught by tests/test_gpu_integrators.py).  The Hopper must NOT: unrolled under its 256-register cap it
+        // spills six times the algorithmic bytes to scratch.
+        auto stage = [&](int st) __attribute__((always_inline)) {
             Body::accel(qs, vs, ctrl, m, R(0), acc, trig);
             const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);
             const R h = dt * (st == 2 ? R(1) : R(0.5));  // step to the NEXT stage state
@@ -131,6 +133,12 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
                 qs[i] = fma_r(h, vs[i], q[i]);
                 vs[i] = fma_r(h, acc[i], v[i]);
             }
+        };
+        if constexpr (Body::kUnrollRK4) {
+            stage(0), stage(1), stage(2), stage(3);
+        } else {
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) stage(st);
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) s[i] = fma_r(dt, dq[i], q[i]), s[NV + i] = fma_r(dt, dv[i], v[i]);

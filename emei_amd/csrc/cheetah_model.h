@@ -489,6 +489,7 @@ struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kUnrollRK4 = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;

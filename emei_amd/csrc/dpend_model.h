@@ -66,6 +66,7 @@ struct DPendBody {
     using real = R;
     using Model = dpend::Model;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kUnrollRK4 = false;
     static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;

@@ -306,6 +306,7 @@ struct HopperBody {
     using real = R;
     using Model = hopper::Model;
     static constexpr int kMinWavesPerEU = 2;
+    static constexpr bool kUnrollRK4 = false;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 12, NO = 12, NA = 3;

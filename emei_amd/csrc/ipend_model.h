@@ -62,6 +62,7 @@ struct InvPendBody {
     using real = R;
     using Model = ipend::Model;
     static constexpr int kMinWavesPerEU = 1;
+    static constexpr bool kUnrollRK4 = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 4, NO = 4, NA = 1;
