@@ -32,6 +32,10 @@ FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
 ABI_VERSION = 2
+# enum emei_kernel_id (emei_last_rollout_kernel)
+KERNEL_NAMES = {0: "none", 1: "pend_rollout_staged_kernel<freq1>", 2: "pend_rollout_staged_kernel", 3: "pend_rollout_kernel<full>",
+                4: "pend_rollout_kernel", 5: "body_rollout_kernel", 6: "body_rollout_kernel<rk4>"}
+KERNEL_PEND_STAGED_FREQ1, KERNEL_PEND_STAGED, KERNEL_PEND_GENERIC_FULL, KERNEL_PEND_GENERIC, KERNEL_BODY, KERNEL_BODY_RK4 = 1, 2, 3, 4, 5, 6
 # enum emei_integrator (mujoco_env.py:70-79) / enum emei_noise_layout
 INTEGRATORS = {"euler": 0, "semi_implicit_euler": 1, "rk4": 2}
 NOISE_IID, NOISE_SHARED = 0, 1
@@ -79,6 +83,8 @@ SYMBOLS = {
     "emei_abi_version": (C.c_int, []),
     "emei_env_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emei_reset": (C.c_int, [_vp, _u64, _vp]),
+    "emei_set_seed": (C.c_int, [_vp, _u64]),
+    "emei_last_rollout_kernel": (C.c_int, [_vp]),
     "emei_set_state": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "emei_get_state": (C.c_int, [_vp, _vp, _vp]),
     "emei_get_obs": (C.c_int, [_vp, _vp, _vp]),

@@ -26,6 +26,7 @@ struct emei_env {
     int32_t* frozen_steps;
     uint32_t* frozen_episode;
     bool has_state, frozen;
+    int last_kernel;  // enum emei_kernel_id of the last emei_step / emei_rollout
     PendParams pend;
     const void* trig;
 };
@@ -192,7 +193,8 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
         return fail(EMEI_ERR_INVALID, "emei_create: HalfCheetahRunning has only the two reward weights");
     int od, ad, sd;
     if (emei_env_dims(cfg->env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
-    if (cfg->n_envs <= 0 || cfg->n_envs > (int64_t)1 << 31)
+    // the kernels index envs with uint32_t lane indices and int32 done lists: n_envs < 2^31
+    if (cfg->n_envs <= 0 || cfg->n_envs >= (int64_t)1 << 31)
         return fail(EMEI_ERR_INVALID, "emei_create: n_envs=%lld out of range", (long long)cfg->n_envs);
     if (cfg->freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_create: freq_rate=%d < 1", cfg->freq_rate);
     if (!(cfg->real_time_scale > 0)) return fail(EMEI_ERR_INVALID, "emei_create: real_time_scale must be > 0");
@@ -331,6 +333,17 @@ extern "C" EMEI_API int emei_reset(emei_env* h, uint64_t seed, void* stream) {
     return EMEI_OK;
 }
 
+extern "C" EMEI_API int emei_set_seed(emei_env* h, uint64_t seed) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_set_seed: null handle");
+    h->cfg.seed = seed;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_last_rollout_kernel(emei_env* h) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_last_rollout_kernel: null handle");
+    return h->last_kernel;
+}
+
 extern "C" EMEI_API int emei_set_state(emei_env* h, const double* state_aos, int reset_counters, void* stream) {
     if (!h || !state_aos) return fail(EMEI_ERR_INVALID, "emei_set_state: null argument");
     EMEI_ON_DEVICE(h, "emei_set_state");
@@ -426,6 +439,7 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
         L.done_out = done_out;
         L.n_steps = n_steps;
         L.flags = flags;
+        L.selected = &h->last_kernel;
         rc = pend_launch(L);
     } else {
         BodyLaunch L = body_base(h, stream);
@@ -436,6 +450,7 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
         L.done_out = done_out;
         L.n_steps = n_steps;
         L.flags = flags;
+        L.selected = &h->last_kernel;
         rc = body_launch(L);
     }
     return rc == EMEI_OK ? rc : fail(rc, "emei_rollout: launch failed (%s)", hipGetErrorString(hipGetLastError()));

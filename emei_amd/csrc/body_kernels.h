@@ -173,6 +173,7 @@ struct BodyLaunch {
     EnvParams env_params;
     const void* trig = nullptr;
     hipStream_t stream = nullptr;
+    int* selected = nullptr;  // out: enum emei_kernel_id of the rollout kernel launched
 };
 int body_launch(const BodyLaunch& L);  // body_dispatch.hip
 
@@ -465,6 +466,7 @@ static int launch_body(const BodyLaunch& L) {
                 hipLaunchKernelGGL((body_rollout_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, a);
             else
                 hipLaunchKernelGGL((body_rollout_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, a);
+            if (L.selected) *L.selected = L.integrator == EMEI_INTEG_RK4 ? EMEI_KERNEL_BODY_RK4 : EMEI_KERNEL_BODY;
             break;
         }
         case BODY_OP_RESET:

@@ -31,6 +31,7 @@ struct PendLaunch {
     uint64_t seed = 0, env_offset = 0;
     PendParams p;
     hipStream_t stream = nullptr;
+    int* selected = nullptr;  // out: enum emei_kernel_id of the rollout kernel launched (emei_last_rollout_kernel)
 };
 
 // pendulum_kernels.hip

@@ -409,20 +409,24 @@ __global__ void __launch_bounds__(kBlock)
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <class Env, typename ActT>
-static void launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
+static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
     const bool full = a.obs_out && a.reward_out && a.done_out;
     if (full && a.n_steps >= kStage && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
         aligned16(a.reward_out) && aligned16(a.done_out))
     {
-        if (a.freq_rate == 1)
+        if (a.freq_rate == 1) {
             hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
-        else
-            hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+            return EMEI_KERNEL_PEND_STAGED_FREQ1;
+        }
+        hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+        return EMEI_KERNEL_PEND_STAGED;
     }
-    else if (full)
+    if (full) {
         hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+        return EMEI_KERNEL_PEND_GENERIC_FULL;
+    }
+    hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
+    return EMEI_KERNEL_PEND_GENERIC;
 }
 
 // host-side dispatch over (env id, precision)
@@ -451,18 +455,21 @@ static int launch_env(const PendLaunch& L) {
     a.p = Env::make_params(L.p);
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
-        case PEND_OP_ROLLOUT:
+        case PEND_OP_ROLLOUT: {
             // discrete envs take uint8/int32/int64 actions, continuous envs float32
+            int sel;
             if constexpr (Env::kDiscrete) {
-                if (L.action_dtype == EMEI_ACT_U8) launch_rollout_full<Env, uint8_t>(a, grid, L.stream);
-                else if (L.action_dtype == EMEI_ACT_I32) launch_rollout_full<Env, int32_t>(a, grid, L.stream);
-                else if (L.action_dtype == EMEI_ACT_I64) launch_rollout_full<Env, int64_t>(a, grid, L.stream);
+                if (L.action_dtype == EMEI_ACT_U8) sel = launch_rollout_full<Env, uint8_t>(a, grid, L.stream);
+                else if (L.action_dtype == EMEI_ACT_I32) sel = launch_rollout_full<Env, int32_t>(a, grid, L.stream);
+                else if (L.action_dtype == EMEI_ACT_I64) sel = launch_rollout_full<Env, int64_t>(a, grid, L.stream);
                 else return EMEI_ERR_INVALID;
             } else {
                 if (L.action_dtype != EMEI_ACT_F32) return EMEI_ERR_INVALID;
-                launch_rollout_full<Env, float>(a, grid, L.stream);
+                sel = launch_rollout_full<Env, float>(a, grid, L.stream);
             }
+            if (L.selected) *L.selected = sel;
             break;
+        }
         case PEND_OP_RESET:
             hipLaunchKernelGGL(pend_reset_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps,
                                L.episode, L.n, L.seed, L.env_offset, a.p);

@@ -109,6 +109,14 @@ class Engine:
     def reset(self, seed=0):
         L.check(L.lib().emei_reset(self._h, int(seed) & (2**64 - 1), _stream()))
 
+    def set_seed(self, seed):
+        """Re-key the device reset generator (auto-reset episodes) without touching the state."""
+        L.check(L.lib().emei_set_seed(self._h, int(seed) & (2**64 - 1)))
+
+    def last_kernel(self):
+        """enum emei_kernel_id of the kernel the last step / rollout launched (_lib.KERNEL_NAMES)."""
+        return int(L.lib().emei_last_rollout_kernel(self._h))
+
     @_on_device
     def set_state(self, state, reset_counters=True):
         st = torch.as_tensor(state, dtype=torch.float64, device=self.device).contiguous()

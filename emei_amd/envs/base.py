@@ -45,6 +45,7 @@ class HipEnv(EmeiEnv):
         self._env_index_offset = int(env_index_offset)
         self._engine = None
         self._np_random = None
+        self._dev_seed_base, self._dev_seed_count = None, 0  # key of the device reset generator (see _next_device_seed)
         self.state = None  # `self.state is not None` after reset (base_control.py:67)
         EmeiEnv.__init__(self, env_params=dict(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator))
 
@@ -94,16 +95,36 @@ class HipEnv(EmeiEnv):
     def _state_to_obs_np(self, state: np.ndarray) -> np.ndarray:
         return state.copy()
 
+    def _next_device_seed(self):
+        """Key of the device reset generator for the episodes that follow this reset().  The device draws the
+        initial state of every auto-reset episode from Philox(key, env, episode), so the key must follow the
+        seed the caller passed (gym: reset(seed=) re-seeds everything random in the env) and must differ
+        between successive un-seeded resets, or every reset() would replay the same post-reset episodes.
+        reset(seed=s) -> s; the k-th un-seeded reset after it -> splitmix64(s + k).  np_random is NOT consumed:
+        its stream stays draw-for-draw the reference's (base_control.py:38-47)."""
+        if self._dev_seed_base is None:
+            self._dev_seed_base = int(np.random.SeedSequence().entropy) & (2**64 - 1)
+        k, self._dev_seed_count = self._dev_seed_count, self._dev_seed_count + 1
+        if k == 0:
+            return self._dev_seed_base
+        z = (self._dev_seed_base + k * 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+
     # -- reset / step -------------------------------------------------------------------------------
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
         if seed is not None:
             self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+            self._dev_seed_base, self._dev_seed_count = int(seed) & (2**64 - 1), 0
+        dev_seed = self._next_device_seed()
         if options and options.get("device_rng"):
             # perf path: counter-based generator on the device, no host round trip
-            self.engine.reset(0 if seed is None else seed)
+            self.engine.reset(dev_seed)
             self.state = True
             return (self._obs_single() if self.num_envs == 1 else self.engine.get_obs()), {}
         init = self._host_init_state(self.num_envs)
+        self.engine.set_seed(dev_seed)
         self.engine.set_state(init)
         self.state = True
         if self.num_envs == 1:

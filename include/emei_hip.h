@@ -168,6 +168,11 @@ EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream);
 EMEI_API int emei_freeze(emei_env* h, void* stream);
 EMEI_API int emei_unfreeze(emei_env* h, void* stream);
 
+/* Re-key the device reset generator without touching the state: the seed of Env.reset(seed=) reaches the
+ * handle also when the initial state itself is drawn on the host and uploaded with emei_set_state
+ * (base_control.py:38-47: gym seeds np_random, every later auto-reset episode must depend on it too). */
+EMEI_API int emei_set_seed(emei_env* h, uint64_t seed);
+
 /* -- the hot path ---------------------------------------------------------------------------- */
 /* Env.step(action) for all n_envs instances (base_control.py:61-83; mujoco_env.py:157-167):
  *   actions   [n_envs] (discrete) or [n_envs, act_dim] (continuous), dtype per action_dtype
@@ -184,6 +189,19 @@ EMEI_API int emei_step(emei_env* h, const void* actions, int action_dtype, float
  * Results are identical to n_steps calls of emei_step. */
 EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* actions, int action_dtype, float* obs_out,
                  float* reward_out, uint8_t* done_out, uint32_t flags, void* stream);
+
+/* Which kernel the LAST emei_step / emei_rollout of this handle launched (enum emei_kernel_id): a debug /
+ * test getter, so that a parity test can assert that the path it checked is the path bench.py times. */
+enum emei_kernel_id {
+    EMEI_KERNEL_NONE = 0,
+    EMEI_KERNEL_PEND_STAGED_FREQ1 = 1, /* pend_rollout_staged_kernel<Env, ActT, true>  (freq_rate == 1) */
+    EMEI_KERNEL_PEND_STAGED = 2,       /* pend_rollout_staged_kernel<Env, ActT, false> */
+    EMEI_KERNEL_PEND_GENERIC_FULL = 3, /* pend_rollout_kernel<Env, ActT, true>: ragged n, short T or unaligned buffers */
+    EMEI_KERNEL_PEND_GENERIC = 4,      /* pend_rollout_kernel<Env, ActT, false>: some output pointer is NULL */
+    EMEI_KERNEL_BODY = 5,              /* body_rollout_kernel<Body, false> (euler / semi-implicit euler) */
+    EMEI_KERNEL_BODY_RK4 = 6           /* body_rollout_kernel<Body, true> */
+};
+EMEI_API int emei_last_rollout_kernel(emei_env* h);
 
 /* Sorted indices of the envs whose last step reported done (wavefront-ballot compaction of the done
  * masks the step kernels leave behind): idx_out [n_envs] int32 (first *count_out entries valid),

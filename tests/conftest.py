@@ -45,3 +45,31 @@ def rel_err(a, b, floor=1.0):
     d = np.where(both_nan | same_inf, 0.0, d)
     d = np.where(np.isnan(d), np.inf, d)
     return float(d.max()) if d.size else 0.0
+
+
+def oracle_autoreset_rollout(variant, s0, acts, seed, env_ids, max_steps, fr=1, dt=0.02):
+    """Oracle restatement of a device rollout WITH auto-reset for the envs `env_ids` (GLOBAL indices = the
+    counter word of the device reset generator): step with the float64 reference arithmetic
+    (oracle/emei_oracle.c, pinned bit-exact to the reference by tests/golden); on done re-initialise from the
+    Philox spec, i.e. identical reset injection.  s0 [k,4], acts [T,k] -> obs [T,k,4], rew [T,k], done [T,k], state."""
+    from oracle import oracle as O
+
+    T, N = acts.shape
+    env_ids = np.asarray(env_ids, np.int64)
+    st = np.array(s0, np.float64)
+    steps = np.zeros(N, np.int64)
+    episode = np.zeros(N, np.int64)
+    obs = np.empty((T, N, 4))
+    rew = np.empty((T, N))
+    done = np.empty((T, N), np.uint8)
+    for t in range(T):
+        st, r, term = O.cartpole_step(variant, st, acts[t], fr, dt)
+        steps += 1
+        trunc = (steps >= max_steps) if max_steps > 0 else np.zeros(N, bool)
+        d = term.astype(np.uint8) | (trunc.astype(np.uint8) << 1)
+        obs[t], rew[t], done[t] = st, r, d
+        for i in np.nonzero(d)[0]:
+            episode[i] += 1
+            steps[i] = 0
+            st[i] = O.cartpole_init_f32(variant, seed, int(env_ids[i]), int(episode[i])).astype(np.float64)
+    return obs, rew, done, st

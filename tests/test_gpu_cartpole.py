@@ -116,28 +116,9 @@ def test_step_before_reset_asserts():
 
 # ------------------------------------------------------------------------------------------------
 def _oracle_autoreset_rollout(variant, s0, acts, seed, offset, max_steps, fr=1, dt=0.02):
-    """Oracle restatement of a device rollout WITH auto-reset: step with the float64 reference
-    arithmetic; on done re-initialise from the Philox spec (identical reset injection)."""
-    from oracle import oracle as O
+    from conftest import oracle_autoreset_rollout
 
-    T, N = acts.shape
-    st = np.array(s0, np.float64)
-    steps = np.zeros(N, np.int64)
-    episode = np.zeros(N, np.int64)
-    obs = np.empty((T, N, 4))
-    rew = np.empty((T, N))
-    done = np.empty((T, N), np.uint8)
-    for t in range(T):
-        st, r, term = O.cartpole_step(variant, st, acts[t], fr, dt)
-        steps += 1
-        trunc = (steps >= max_steps) if max_steps > 0 else np.zeros(N, bool)
-        d = term.astype(np.uint8) | (trunc.astype(np.uint8) << 1)
-        obs[t], rew[t], done[t] = st, r, d
-        for i in np.nonzero(d)[0]:
-            episode[i] += 1
-            steps[i] = 0
-            st[i] = O.cartpole_init_f32(variant, seed, offset + i, int(episode[i])).astype(np.float64)
-    return obs, rew, done, st
+    return oracle_autoreset_rollout(variant, s0, acts, seed, offset + np.arange(acts.shape[1]), max_steps, fr, dt)
 
 
 @pytest.mark.parametrize("name", ["swingup", "balancing"])

@@ -19,12 +19,18 @@ def test_single_env_reproduces_reference_trajectory(cartpole_golden, name, cls, 
     env = cls(freq_rate=fr)
     obs, info = env.reset(seed=0)
     assert info == {} and obs.dtype == np.float64 and np.array_equal(obs, g[tag + "_states"][0])
-    T = 300
+    T = len(g[tag + "_actions"])
+    assert T == 1000  # all of config 1: CartPoleSwingUp-v0's max_episode_steps (register_env.py:19-23)
     for t in range(T):
         obs, reward, terminal, truncated, info = env.step(int(g[tag + "_actions"][t]))
         assert isinstance(reward, np.float64) and isinstance(terminal, np.bool_) and truncated is False and info == {}
-        assert rel_err(obs, g[tag + "_states"][t + 1], floor=1e-30) <= 1e-9
-        assert abs(reward - g[tag + "_reward"][t]) <= 1e-6 and bool(terminal) == bool(g[tag + "_terminal"][t])
+        # the float64 state follows the reference to ~1e-9 over the first 300 steps; the chaotic pendulum
+        # amplifies the last-bit differences of sincos afterwards: north-star tolerance 1e-5 over all 1000
+        if t < 300:
+            assert rel_err(obs, g[tag + "_states"][t + 1], floor=1e-30) <= 1e-9, t
+        else:
+            assert rel_err(obs, g[tag + "_states"][t + 1]) <= 1e-5, t
+        assert abs(reward - g[tag + "_reward"][t]) <= 1e-6 and bool(terminal) == bool(g[tag + "_terminal"][t]), t
 
 
 def test_reference_behaviour_tests_cartpole():
@@ -99,3 +105,23 @@ def test_inverted_pendulum_env_api():
     assert terminal and reward == 1.0
     with pytest.raises(ValueError):
         env.step(np.zeros(2, np.float32))
+
+
+def test_reset_seed_reaches_device_generator():
+    """reset(seed=) also keys the device generator that draws every auto-reset episode's initial state: two seeds
+    give different episode-1 initial observations, the same seed the same, and successive un-seeded resets differ
+    (the host-reset path used to leave the key at 0)."""
+    env = emei_amd.CartPoleBalancingEnv(num_envs=64, auto_reset=True, max_episode_steps=5)
+    acts = torch.zeros((5, 64), dtype=torch.uint8, device=env.engine.device)
+
+    def episode1_init(seed):
+        env.reset(seed=seed)
+        obs, rew, term, trunc = env.rollout(acts)
+        assert bool((trunc[-1] | term[-1]).all())  # TimeLimit 5: every env was re-initialised on the device
+        return env.engine.get_obs().clone()
+
+    a, b, a2 = episode1_init(1), episode1_init(2), episode1_init(1)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    env.reset()  # un-seeded reset after reset(seed=1): a fresh key, np_random untouched
+    env.rollout(acts)
+    assert not torch.equal(env.engine.get_obs(), a)
