@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 // partial-line byte stores.  LDS slices are wave-private (LDS operations of one wave execute in
 // order), so there is no barrier anywhere.
 constexpr int kStage = 16;
+constexpr int kTileWaitKeep = kStage;  // VMEM operations left in flight when a staged action tile is retired
 
 template <class Env, typename ActT, bool FREQ1>
 __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
@@ -289,9 +290,15 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
                 maybe_reset();
             }
         }
-        // retire the tile: it is older than this tile's stores (16 obs + >= 3 reward flushes), so
-        // leaving the 19 youngest operations in flight still covers every LDS-DMA load
-        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        // Retire the tile.  Loads, stores and LDS-DMA share one in-order counter, and the tile's loads were
+        // issued before ALL of this tile's stores, of which the kStage observation stores are unconditional
+        // (the reward / done flushes add 3 to 5 more): leaving the kTileWaitKeep = kStage youngest operations
+        // in flight therefore covers every LDS-DMA load, and what it additionally waits for was issued at
+        // least kStage - 3 steps ago.  The count is DERIVED from the tile constants — a hand-written 19
+        // (16 + the first tile's 3 reward flushes) was exact with zero margin — and tests/test_isa_guards.py
+        // checks the emitted immediate and the stores of the loop body in the shipped code object.
+        static_assert(kTileWaitKeep == kStage && kTileWaitKeep < 64, "one unconditional obs store per staged step");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kTileWaitKeep) : "memory");
     }
     if (t0 > 0) {
         store_rew_rows(t0 - 4, rew_pend);

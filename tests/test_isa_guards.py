@@ -1,0 +1,142 @@
+"""Static audit of the SHIPPED gfx950 code objects (libemei_hip.so) for the assumptions the hand-scheduled
+kernels rest on (cdna_hip_programming.md §5.7 items 1 and 4: hipcc neither counts nor protects what an
+`asm` statement loads).  Runs without a GPU: llvm-objdump on the offload bundles of the built library.
+
+For every `pend_rollout_staged_kernel` instantiation:
+  * no scratch traffic and no AGPR moves (the kernel's register budget is what DESIGN.md says it is);
+  * the tile-retire wait is `s_waitcnt vmcnt(kStage)` and the tile loop it closes carries at least one
+    16-byte store per unrolled step (pendulum_kernels.h: kTileWaitKeep is derived from those stores);
+  * no instruction touches the destination registers of an LDS read (`ds_read_b128`: the {sin,cos} table entry
+    of emei_device.h:sincos_begin_ctx and the staged flushes) before a wait on lgkmcnt — a compiler copy or spill
+    of the in-flight registers would read garbage.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "emei_amd", "libemei_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+K_STAGE = 16  # pendulum_kernels.h: kStage == kTileWaitKeep
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+
+_INS = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+
+
+def _vregs(text):
+    """set of VGPR numbers named in an operand string: v12, v[4:7]"""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+@pytest.fixture(scope="module")
+def functions(tmp_path_factory):
+    """{mangled name: [(addr, mnemonic, operands)]} over every gfx950 code object bundled in the library."""
+    d = tmp_path_factory.mktemp("isa")
+    lib = shutil.copy(LIB, d)
+    subprocess.check_call([OBJDUMP, "--offloading", lib], stdout=subprocess.DEVNULL, cwd=d)
+    funcs = {}
+    for f in sorted(os.listdir(d)):
+        if "gfx950" not in f:
+            continue
+        txt = subprocess.check_output([OBJDUMP, "-d", os.path.join(d, f)], text=True)
+        cur = None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+                continue
+            m = _INS.match(line)
+            if m and cur is not None:
+                cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return funcs
+
+
+def _staged(functions):
+    fs = {k: v for k, v in functions.items() if "pend_rollout_staged_kernel" in k}
+    # CartPole x {u8, i32, i64} x {FREQ1, loop} x 2 variants x 2 precisions + InvPend x f32 x 2 x 4 x 2
+    assert len(fs) >= 24 + 16, sorted(fs)
+    return fs
+
+
+def test_staged_kernels_have_no_scratch_and_no_agpr_traffic(functions):
+    for name, ins in _staged(functions).items():
+        bad = [(hex(a), m) for a, m, o in ins if m.startswith("scratch_") or m.startswith("v_accvgpr")]
+        assert not bad, (name, bad[:4])
+
+
+def _loop_through(ins, k0):
+    """indices of the instructions that lie on a cycle through instruction k0 (the loop it belongs to): forward-
+    reachable from k0 and able to reach k0, over fall-through and branch edges (hipcc lays blocks out of line, so
+    address order says nothing)."""
+    at = {a: k for k, (a, m, o) in enumerate(ins)}
+    succ = [[] for _ in ins]
+    for k, (a, m, o) in enumerate(ins):
+        if m.startswith("s_cbranch") or m == "s_branch":
+            off = int(o.split()[0])
+            off = off - 65536 if off >= 32768 else off
+            succ[k].append(at[a + 4 + 4 * off])
+        if m not in ("s_branch", "s_endpgm", "s_setpc_b64") and k + 1 < len(ins):
+            succ[k].append(k + 1)
+    pred = [[] for _ in ins]
+    for k, ss in enumerate(succ):
+        for t in ss:
+            pred[t].append(k)
+
+    def reach(adj):
+        seen, todo = set(), [k0]
+        while todo:
+            for t in adj[todo.pop()]:
+                if t not in seen:
+                    seen.add(t)
+                    todo.append(t)
+        return seen
+
+    return reach(succ) & reach(pred)
+
+
+def test_tile_retire_wait_is_derived_from_the_obs_stores(functions):
+    for name, ins in _staged(functions).items():
+        counted = [(k, int(re.fullmatch(r"vmcnt\((\d+)\)", o).group(1))) for k, (a, m, o) in enumerate(ins)
+                   if m == "s_waitcnt" and re.fullmatch(r"vmcnt\((\d+)\)", o)]
+        # the hand-written retire wait is the only counted wait that leaves >= 8 operations in flight
+        retire = [(k, n) for k, n in counted if n >= 8]
+        assert len(retire) == 1 and retire[0][1] == K_STAGE, (name, counted)
+        loop = _loop_through(ins, retire[0][0])
+        assert loop, name  # the wait closes a loop (the tile loop)
+        loads = [k for k in loop if ins[k][1] == "global_load_lds_dwordx4"]
+        stores = [k for k in loop if ins[k][1] == "global_store_dwordx4"]
+        other_waits = [ins[k][2] for k in loop if ins[k][1] == "s_waitcnt" and "vmcnt" in ins[k][2] and k != retire[0][0]]
+        assert len(loads) >= 1, name  # the next tile's LDS-DMA is issued inside the loop it is retired in
+        # 4 unrolled steps per trip of the rolled group loop (kStage / 4 trips): >= 4 sixteen-byte obs stores in the loop
+        assert len(stores) >= 4, (name, len(stores))
+        # nothing else in the tile loop drains the vector-memory counter (that would put store latency on the serial chain)
+        assert not other_waits, (name, other_waits)
+        # the prologue tile is complete before the loop is entered
+        first_load = min(k for k, (a, m, o) in enumerate(ins) if m == "global_load_lds_dwordx4")
+        assert any(n == 0 and k > first_load for k, n in counted), name
+
+
+def test_no_instruction_touches_an_lds_read_destination_before_its_wait(functions):
+    checked = 0
+    for name, ins in _staged(functions).items():
+        for k, (a, m, o) in enumerate(ins):
+            if m != "ds_read_b128":
+                continue
+            dst = _vregs(o.split(",")[0])
+            assert len(dst) == 4, (name, o)
+            for a2, m2, o2 in ins[k + 1:]:
+                if m2 == "s_waitcnt" and "lgkmcnt" in o2:
+                    break
+                if m2.startswith("s_cbranch") or m2 in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    break  # leaves the straight line: the reads of this kernel are waited for inside their block
+                assert not (_vregs(o2) & dst), f"{name}: {m2} {o2} at {a2:#x} touches {sorted(dst)} of the ds_read_b128 at {a:#x}"
+            checked += 1
+    assert checked >= 40
