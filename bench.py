@@ -7,9 +7,16 @@ RCCL).  Rank 0 prints ONE JSON line.
 
 A bench "step" = one pass of the hot path over one batch of synthetic input: `emei_rollout` of
 `--horizon` (default 1000 = max_episode_steps of CartPoleSwingUp-v0, register_env.py:19-23) env-steps
-for every env of the shard, in one launch, with device-side auto-reset.
+for every env of the shard, with device-side auto-reset.
 value = env-steps/s over all ranks = n_gpus * envs_per_gpu * horizon * K / time.
 Inputs (state, actions) are resident in HBM before the timed region; outputs land in HBM.
+
+N = 1 is BASELINE configs[1] (65 536 CartPoleSwingUp envs, one launch per horizon).  N > 1 shards 131 072
+envs per GPU, so that N = 8 IS BASELINE configs[4] (1 048 576 envs), and exchanges the batched observation
+return over RCCL: by default (`--gather per_chunk`) the whole [T, n, 4] observation block of a pass is
+all-gathered in chunks of `--chunk` steps on a dedicated stream under the following launches; the collective's
+inbound volume and rate are reported beside the HBM roofline.  `--gather final` exchanges only the last
+observation of a pass, `--gather per_step` one [n, 4] block per env-step (one emei_step launch each).
 """
 import argparse
 import json
@@ -22,6 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+XGMI_PEAK_GBS = 7 * 153.0  # 7 point-to-point xGMI links per GPU x ~153 GB/s: inbound peak of a direct all-gather
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+MULTI_GPU_SHARD = 131072  # BASELINE configs[4]: 1 048 576 envs / 8 GPUs
 
 WORKLOADS = {
     # name: (env, envs_per_gpu, freq_rate, dt, horizon, act bytes, obs_dim, act_dim)
@@ -78,7 +88,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cartpole_swingup", choices=sorted(WORKLOADS))
-    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--envs-per-gpu", type=int, default=None,
+                    help="default: the workload's single-GPU size; 131 072 for the CartPole workloads when --gpus > 1")
+    ap.add_argument("--gather", default=None, choices=["final", "per_chunk", "per_step"],
+                    help="what the observation return exchanges across ranks (default: per_chunk when --gpus > 1, final otherwise)")
+    ap.add_argument("--chunk", type=int, default=125, help="steps per launch / per all-gather with --gather per_chunk")
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
     ap.add_argument("--integrator", default=None, choices=["euler", "semi_implicit_euler", "rk4"],
@@ -123,12 +137,19 @@ def main():
     from emei_amd.sharding import ShardedRollout
 
     w = dict(WORKLOADS[a.workload])
-    N = a.envs_per_gpu or w["n"]
+    sharded_cartpole = world > 1 and a.workload.startswith("cartpole")
+    N = a.envs_per_gpu or (MULTI_GPU_SHARD if sharded_cartpole else w["n"])
     T = a.horizon or w["horizon"]
     env = w["env"]
+    gather = a.gather or ("per_chunk" if world > 1 else "final")
+    chunk = a.chunk if T % a.chunk == 0 else T
     sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
                         rank=rank, world=world, device=local_rank, seed=0,
-                        integrator=a.integrator or w.get("integrator", "euler"))
+                        integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk)
+    desc = w["desc"]
+    if sharded_cartpole and a.workload == "cartpole_swingup" and N == MULTI_GPU_SHARD:
+        desc = (f"CartPoleSwingUp-v0, {world * N} parallel envs sharded {world}xMI355X ({N} per GPU) with RCCL all-gather of obs"
+                + (" (BASELINE configs[4])" if world == 8 else " (BASELINE configs[4]'s shard size)"))
     sr.make_synthetic_inputs()
 
     # Untimed settle phase before the W warm-up passes: after idling, the first ~10-30 ms of back-to-back
@@ -174,35 +195,58 @@ def main():
     # average launch duration of the dominant kernel over the timed region: at one GPU a pass is
     # exactly one rollout launch, so the event pair around the K passes / K is the kernel's duration
     # (plus the ~1.5 us dependent-launch gap); with several ranks the all-gather sits between launches
-    kernel_ms = ev0.elapsed_time(ev1) / a.steps if world == 1 else sr.timed_launches_ms(a.steps)
+    single_launch = world == 1 and sr.n_chunks == 1
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps if single_launch else sr.timed_launches_ms(a.steps)
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / el
     bpes = algorithmic_bytes_per_env_step(sr.obs_dim, sr.action_bytes)
-    achieved = bpes * N * T / (kernel_ms * 1e-3) / 1e9
+    T_launch = sr.chunk  # env-steps per env of ONE launch (= the horizon unless the pass is chunked)
+    achieved = bpes * N * T_launch / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic.json, written from
     # tools/collect_profiles.sh output with the gfx950 FETCH_SIZE correction); only valid for the
     # default shape it was collected on
-    traffic = None
+    traffic = valu = None
+    prof = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and N == w["n"] and T == w["horizon"] and a.precision == "ref":
+    if os.path.exists(tpath) and N == w["n"] and T_launch == w["horizon"] and a.precision == "ref" and not a.integrator:
         try:
-            traffic = json.load(open(tpath)).get(a.workload, {}).get("bytes_per_launch")
+            prof = json.load(open(tpath)).get(a.workload, {})
+            traffic, valu = prof.get("bytes_per_launch"), prof.get("valu_insts_per_launch")
         except Exception:
-            traffic = None
+            prof = {}
 
     out = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if a.precision == "ref" else "f32", "data": "synthetic",
-        "config": {"workload": w["desc"], "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
-                   "real_time_scale": w["dt"], "settle_ms_before_warmup": a.settle_ms, "integrator": a.integrator or w.get("integrator", "euler"), "api": "emei_rollout (one launch per horizon, device auto-reset)",
+        "config": {"workload": desc, "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
+                   "real_time_scale": w["dt"], "settle_ms_before_warmup": a.settle_ms, "integrator": a.integrator or w.get("integrator", "euler"), "api": f"emei_rollout ({'one launch per horizon' if sr.n_chunks == 1 else f'{sr.n_chunks} launches of {sr.chunk} steps per horizon'}, device auto-reset)",
                    "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
-                   "obs_allgather": "final obs of each pass over RCCL, on a dedicated stream under the next pass's rollout" if world > 1 else "n/a (1 GPU)"},
+                   "gather": gather, "chunk_steps": sr.chunk,
+                   "obs_allgather": ({"final": "last [n,obs_dim] observation of each pass",
+                                      "per_chunk": f"the whole [T,n,obs_dim] observation return, one all-gather per {sr.chunk}-step chunk",
+                                      "per_step": "the [n,obs_dim] observation of every env-step, one all-gather per step"}[gather]
+                                     + " over RCCL, on a dedicated stream under the following launches") if world > 1 else "n/a (1 GPU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": sr.kernel_name,
-                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes,
-                     "algorithmic_bytes_per_launch": bpes * N * T},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": (f"{prof.get('profile', 'profiles/')} via profiles/traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE "
+                                        "passes of this command, collected separately, NOT measured in this run") if traffic else None,
+                     "kernel": sr.kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes,
+                     "algorithmic_bytes_per_launch": bpes * N * T_launch},
     }
+    if valu:
+        # second roofline for the VALU-bound bodies: executed vector instructions per launch (SQ_INSTS_VALU, counted per
+        # wave) x 4 cycles of issue each (MI355X_MICROARCH.md: one wave issues a VALU instruction per >= 4 cycles; f64 FMA
+        # and f32 alike) / (SIMDs x max clock x kernel time) = the fraction of the chip's vector-issue slots in use
+        out["roofline_valu"] = {"bound": "valu_f64", "valu_insts_per_launch": valu, "cycles_per_inst": 4, "simds": SIMDS,
+                                "clock_ghz": CLOCK_GHZ, "frac": valu * 4 / (SIMDS * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3),
+                                "source": f"{prof.get('profile', 'profiles/')} SQ pass via profiles/traffic.json, NOT measured in this run"}
+    if world > 1:
+        gb = sr.gathered_bytes_per_pass
+        out["xgmi"] = {"bound": "xgmi", "inbound_bytes_per_rank_per_pass": gb, "achieved": gb * a.steps / el / 1e9,
+                       "peak": XGMI_PEAK_GBS, "unit": "GB/s", "frac": gb * a.steps / el / 1e9 / XGMI_PEAK_GBS,
+                       "collectives_per_pass": sr.n_chunks if gather != "final" else 1,
+                       "note": "whole-pass average: the all-gathers overlap the rollout launches"}
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

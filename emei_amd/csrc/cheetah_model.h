@@ -489,7 +489,10 @@ struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
     static constexpr int kMinWavesPerEU = 1;
-    static constexpr bool kUnrollRK4 = true;
+#ifndef EMEI_CHEETAH_UNROLL_RK4
+#define EMEI_CHEETAH_UNROLL_RK4 1
+#endif
+    static constexpr bool kUnrollRK4 = EMEI_CHEETAH_UNROLL_RK4 != 0;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;

@@ -4,7 +4,7 @@ Env instances are fully independent (no cross-env term in cartpole.py:48-60 or
 mujoco_env.py:86-109), so the data path has no collective: rank r owns global envs
 [r*n, (r+1)*n), with its own state SoA and a device RNG keyed by the GLOBAL env index, which makes
 results independent of the number of ranks.  The only exchange is the batched observation return:
-an all-gather of the [n, obs_dim] float32 observations (RCCL over xGMI on GPUs; gloo in CPU tests).
+an all-gather of float32 observation blocks (RCCL over xGMI on GPUs; gloo in CPU tests).
 """
 import numpy as np
 import torch
@@ -18,7 +18,8 @@ def shard_bounds(n_global, rank, world):
 
 
 def allgather_obs(local_obs, group=None, out=None):
-    """All-gather equal-sized [n, d] observation shards into [world*n, d] (rank-major = global env order)."""
+    """All-gather equal-sized observation shards ([n, d] or [rows, n, d]) rank-major: `out` is [world * n, d], or
+    [world, rows, n, d] when given (rank r's block at out[r]; for [n, d] shards rank-major IS global env order)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
@@ -27,14 +28,67 @@ def allgather_obs(local_obs, group=None, out=None):
     if out is None:
         out = torch.empty((world * local_obs.shape[0],) + tuple(local_obs.shape[1:]), dtype=local_obs.dtype,
                           device=local_obs.device)
+    # the collective sees the receive buffer in its concatenated form ([world * rows, ...]: same memory as the
+    # rank-major [world, rows, ...]); gloo accepts only that form
+    flat = out.view((world * local_obs.shape[0],) + tuple(local_obs.shape[1:]))
     if dist.get_backend(group) == "gloo" and local_obs.is_cuda:
         # rehearsal path only (gloo has no device all-gather): stage through the host
-        host = torch.empty(out.shape, dtype=out.dtype)
+        host = torch.empty(flat.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, local_obs.cpu().contiguous(), group=group)
-        out.copy_(host)
+        flat.copy_(host)
         return out
-    dist.all_gather_into_tensor(out, local_obs.contiguous(), group=group)
+    dist.all_gather_into_tensor(flat, local_obs.contiguous(), group=group)
     return out
+
+
+class ObsExchange:
+    """Double-buffered all-gather of observation blocks, overlapped with the producer's next launches.
+
+    A block ([rows, n, obs_dim], written on the launch stream into output slot `slot`) is all-gathered on a
+    dedicated stream into one of two rank-major receive buffers ([world, rows, n, obs_dim]).  Three hazards are
+    ordered with events (device tensors; on CPU tensors — the gloo tests — every call is synchronous):
+      ready       launch stream -> comm stream : the producer has written the block
+      done[slot]  comm stream -> launch stream : the gather has READ the block; `fence(slot)` makes the launch
+                                                 stream wait for it before the slot is overwritten
+      receive buffers alternate; gathers are serialised on the comm stream, so buffer b is free again when the
+      gather two collectives later starts (a consumer reads it in between)"""
+
+    def __init__(self, world, rows, n, obs_dim, n_slots, device):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.gathered = [torch.empty((world, rows, n, obs_dim), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._done = [None] * n_slots
+        self.collectives = 0
+
+    def fence(self, slot):
+        if self._done[slot] is not None:
+            torch.cuda.current_stream().wait_event(self._done[slot])
+
+    def exchange(self, slot, block, group=None):
+        buf = self.gathered[self.collectives & 1]
+        self.collectives += 1
+        if not self.cuda:
+            allgather_obs(block, group=group, out=buf)
+            return buf
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ready)
+            allgather_obs(block, group=group, out=buf)
+            done = torch.cuda.Event()
+            done.record(self._comm)
+        self._done[slot] = done
+        return buf
+
+    def last(self, back=0):
+        """receive buffer of the collective `back` before the most recent one (0 or 1)"""
+        return self.gathered[(self.collectives - 1 - back) & 1]
+
+    def wait_all(self):
+        for ev in self._done:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
 
 def synthetic_init_state(env, n_global, lo, hi, seed=0):
@@ -66,16 +120,35 @@ def synthetic_actions(env, horizon, n, rank, world, device, act_dim):
 
 
 class ShardedRollout:
-    """This rank's shard of a fused rollout + the all-gather of the batched observation return."""
+    """This rank's shard of a fused rollout + the all-gather of the batched observation return.
+
+    gather modes (what `run_pass` exchanges; the reference's callers read the observation of EVERY step,
+    zoo/util.py:54-59, so the whole [T, n, obs_dim] return is what a sharded caller needs on every rank):
+      "final"      only the last [n, obs_dim] of a pass (one small collective per horizon)
+      "per_chunk"  the horizon runs as T / chunk launches of `chunk` steps; each chunk's whole
+                   [chunk, n, obs_dim] observation block is all-gathered (rank-major: [world, chunk, n, obs_dim])
+                   on a dedicated stream while the next chunk's rollout runs
+      "per_step"   per_chunk with chunk = 1: one emei_step launch + one [n, obs_dim] all-gather per env-step
+    With one rank nothing is exchanged (unless `force_exchange`: a 1-rank group still runs the collective path,
+    for tests); "per_chunk" / "per_step" still launch per chunk."""
 
     MAX_EPISODE_STEPS = {"CartPoleSwingUp": 1000, "CartPoleBalancing": 500}  # register_env.py:14-23
 
     def __init__(self, env, envs_per_rank, horizon, freq_rate=1, real_time_scale=0.02, precision="ref", rank=0,
-                 world=1, device=0, seed=0, init_noise=None, integrator="euler"):
+                 world=1, device=0, seed=0, init_noise=None, integrator="euler", gather="final", chunk=None,
+                 force_exchange=False):
         from .engine import Engine
 
         self.env, self.n, self.horizon, self.rank, self.world = env, int(envs_per_rank), int(horizon), rank, world
         self.lo, self.hi = rank * self.n, (rank + 1) * self.n
+        if gather not in ("final", "per_chunk", "per_step"):
+            raise ValueError(f"gather={gather!r}")
+        self.gather = gather
+        self.chunk = self.horizon if gather == "final" else (1 if gather == "per_step" else int(chunk or 125))
+        if self.chunk < 1 or self.horizon % self.chunk:
+            raise ValueError(f"chunk {self.chunk} must divide the horizon {self.horizon}")
+        self.n_chunks = self.horizon // self.chunk
+        self.exchanging = world > 1 or bool(force_exchange)
         if init_noise is None:
             init_noise = 0.1 if env == "HalfCheetahRunning" else 5e-3
         self.engine = Engine(env, self.n, freq_rate=freq_rate, real_time_scale=real_time_scale, precision=precision,
@@ -84,10 +157,15 @@ class ShardedRollout:
         self.device = self.engine.device
         self.obs_dim, self.act_dim = self.engine.obs_dim, self.engine.act_dim
         self.seed = seed
-        self.actions = self.out = self.gathered = None
+        self.actions = self.out = self.gathered = self.xchg = None
         self._events = []
-        self.kernel_name = ("body_rollout_kernel" if (env in ("HalfCheetahRunning", "HopperRunning") or "Double" in env or integrator != "euler")
-                            else "pend_rollout_staged_kernel")
+
+    @property
+    def kernel_name(self):
+        """the rollout kernel the last launch selected (emei_last_rollout_kernel)"""
+        from . import _lib as L
+
+        return L.KERNEL_NAMES[self.engine.last_kernel()]
 
     @property
     def action_bytes(self):
@@ -97,6 +175,16 @@ class ShardedRollout:
     def action_dtype_name(self):
         return str(self.actions.dtype).replace("torch.", "")
 
+    @property
+    def gathered_bytes_per_pass(self):
+        """bytes every rank RECEIVES from its peers per pass (the xGMI inbound volume of the observation return)"""
+        rows = self.n if self.gather == "final" else self.n * self.horizon
+        return (self.world - 1) * rows * self.obs_dim * 4
+
+    @property
+    def collectives(self):
+        return self.xchg.collectives if self.xchg is not None else 0
+
     def make_synthetic_inputs(self):
         s0 = synthetic_init_state(self.env, self.world * self.n, self.lo, self.hi, self.seed)
         if s0 is None:
@@ -105,51 +193,46 @@ class ShardedRollout:
             self.engine.set_state(s0)
         self.actions = synthetic_actions(self.env, self.horizon, self.n, self.rank, self.world, self.device, self.act_dim)
         self.out = self.engine.alloc_outputs(self.horizon)
-        if self.world > 1:
-            # The observation return overlaps the NEXT pass's rollout: the shard is copied to one of two
-            # staging buffers on the launch stream and all-gathered from there on a dedicated stream (xGMI
-            # transfers run under the kernel); events fence each buffer before it is reused two passes later.
-            shape = (self.world * self.n, self.obs_dim)
-            self.gathered = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
-            self._stage = [torch.empty((self.n, self.obs_dim), dtype=torch.float32, device=self.device) for _ in range(2)]
-            self._comm = torch.cuda.Stream(device=self.device)
-            self._comm_done = [None, None]
-            self._pass = 0
+        K = self.chunk
+        # per-chunk views of the whole-horizon buffers (contiguous: the leading dimension is the step)
+        self._act_chunks = [self.actions[c * K:(c + 1) * K] for c in range(self.n_chunks)]
+        self._out_chunks = [tuple(o[c * K:(c + 1) * K] for o in self.out) for c in range(self.n_chunks)]
+        if self.exchanging:
+            # a chunk's observation block is gathered straight from the rollout's output slice (slot = chunk index);
+            # "final" copies the last row to a one-row staging buffer first (slot 0)
+            rows = 1 if self.gather == "final" else K
+            self.xchg = ObsExchange(self.world, rows, self.n, self.obs_dim, self.n_chunks, self.device)
+            self.gathered = self.xchg.gathered
+            self._stage = torch.empty((1, self.n, self.obs_dim), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize()
 
     def run_pass(self, record=False):
-        """One rollout launch over the whole horizon, then the batched observation return."""
+        """The whole horizon (one launch, or one per chunk) + the batched observation return of the gather mode.
+        -> the last receive buffer ([world, rows, n, obs_dim], valid once `wait_gathers` has run) or, without an
+        exchange, the local observations of the last chunk."""
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        obs, rew, done = self.engine.rollout(self.actions, auto_reset=True, out=self.out)
+        last = None
+        for c in range(self.n_chunks):
+            if self.exchanging:
+                self.xchg.fence(c)  # the gather that read this slice during the previous pass is over before it is rewritten
+            obs, rew, done = self.engine.rollout(self._act_chunks[c], auto_reset=True, out=self._out_chunks[c])
+            last = obs
+            if self.exchanging and self.gather != "final":
+                last = self.xchg.exchange(c, obs)
         if record:
             e1.record()
             self._events.append((e0, e1))
-        final_obs = obs[-1]
-        if self.world > 1:
-            k = self._pass & 1
-            self._pass += 1
-            main = torch.cuda.current_stream()
-            if self._comm_done[k] is not None:
-                main.wait_event(self._comm_done[k])  # the gather that last read this staging buffer has finished
-            self._stage[k].copy_(final_obs)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(self._comm):
-                self._comm.wait_event(ready)
-                final_obs = allgather_obs(self._stage[k], out=self.gathered[k])
-                done = torch.cuda.Event()
-                done.record(self._comm)
-                self._comm_done[k] = done
-        return final_obs
+        if self.exchanging and self.gather == "final":
+            self._stage.copy_(last[-1:])  # one slot: fence(0) above also covers the staging buffer
+            last = self.xchg.exchange(0, self._stage)
+        return last
 
     def wait_gathers(self):
         """Make the launch stream wait for every outstanding observation all-gather."""
-        if self.world > 1:
-            for ev in self._comm_done:
-                if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
+        if self.exchanging:
+            self.xchg.wait_all()
 
     def mean_kernel_ms(self):
         torch.cuda.synchronize()
@@ -157,15 +240,16 @@ class ShardedRollout:
         return float(np.mean(ts)) if ts else float("nan")
 
     def timed_launches_ms(self, k):
-        """Mean duration of k back-to-back rollout launches bracketed by ONE pair of HIP events on the
-        launch stream (no per-launch marker packets inside the timed span)."""
+        """Mean duration of one rollout launch: k passes of back-to-back launches (no collective) bracketed by ONE
+        pair of HIP events on the launch stream (no per-launch marker packets inside the timed span)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(k):
-            self.engine.rollout(self.actions, auto_reset=True, out=self.out)
+            for c in range(self.n_chunks):
+                self.engine.rollout(self._act_chunks[c], auto_reset=True, out=self._out_chunks[c])
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / k
+        return e0.elapsed_time(e1) / (k * self.n_chunks)
 
     def time_per_step_api(self, n_steps=200):
         """One launch per env-step (emei_step), the gym-style API: launch-bound by construction."""

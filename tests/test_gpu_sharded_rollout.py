@@ -1,0 +1,34 @@
+"""ShardedRollout.run_pass (bench.py's multi-GPU path) on real device buffers, streams and events: every gather
+mode, with 2 ranks sharing the one GPU over gloo (content of every peer block checked) and with a 1-rank RCCL group
+(the collective the 8-GPU run uses).  tests/host/sharded_rollout_check.py is the per-rank program."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROG = os.path.join(ROOT, "tests", "host", "sharded_rollout_check.py")
+
+
+def _run(nproc, port, *args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), PROG, *args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("gather,chunk", [("per_chunk", 16), ("per_chunk", 64), ("per_step", 1), ("final", 0)])
+def test_two_ranks_share_the_gpu_over_gloo(gather, chunk):
+    out = _run(2, 29611, "--backend", "gloo", "--gather", gather, "--chunk", str(max(chunk, 1)),
+               "--horizon", "64" if gather != "per_step" else "24")
+    assert "world=2" in out and "pend_rollout_staged_kernel" in out or gather == "per_step"
+
+
+@pytest.mark.parametrize("gather", ["per_chunk", "final"])
+def test_one_rank_rccl_group(gather):
+    out = _run(1, 29612, "--backend", "nccl", "--gather", gather, "--chunk", "16", "--envs", "65536")
+    assert "world=1 backend=nccl" in out

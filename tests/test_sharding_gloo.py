@@ -58,6 +58,52 @@ def test_allgather_obs_world2():
     assert res == [(0, True, (world * n, 4)), (1, True, (world * n, 4))]
 
 
+def _xchg_worker(rank, world, port, q):
+    """ObsExchange (the buffer rotation under ShardedRollout.run_pass) on CPU tensors: per-chunk blocks of a
+    [T, n, d] return over several passes; every receive buffer must hold every rank's block of that collective."""
+    sys.path.insert(0, ROOT)
+    from emei_amd.sharding import ObsExchange
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, K, n, d = 12, 4, 10, 4
+        x = ObsExchange(world, K, n, d, T // K, "cpu")
+
+        def block(r, p, c):  # what rank r produces for chunk c of pass p
+            return (torch.arange(K * n * d, dtype=torch.float32).reshape(K, n, d) + 1000.0 * r + 100.0 * p + 10.0 * c)
+
+        ok = True
+        for p in range(3):
+            for c in range(T // K):
+                x.fence(c)
+                buf = x.exchange(c, block(rank, p, c))
+                ok &= buf is x.last(0) and all(torch.equal(buf[r], block(r, p, c)) for r in range(world))
+                if x.collectives >= 2:  # the previous collective's buffer is still intact (double buffering)
+                    pp, pc = (p, c - 1) if c > 0 else (p - 1, T // K - 1)
+                    ok &= all(torch.equal(x.last(1)[r], block(r, pp, pc)) for r in range(world))
+        x.wait_all()
+        q.put((rank, bool(ok), x.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_obs_exchange_chunks_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(0, True, 9), (1, True, 9)]
+
+
 def test_shard_bounds_cover_and_balance():
     from emei_amd.sharding import shard_bounds
 

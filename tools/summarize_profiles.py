@@ -25,6 +25,18 @@ def mean_counters(d, pat):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+def pass_duration_us(d, pat):
+    """mean duration of the matching kernel inside a counter pass (its own --kernel-trace): counter collection
+    serialises and slows the dispatches, so cycles of a pass go with the durations of the SAME pass"""
+    files = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    ts = []
+    for f in files[-1:]:
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]:
+                ts.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return sum(ts) / len(ts) if ts else None
+
+
 def main():
     raw, rnd, workload, pat = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     n_envs, horizon, bytes_per_step, waves = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
@@ -45,6 +57,8 @@ def main():
         "algorithmic_bytes_per_launch": alg, "ratio_traffic_over_algorithmic": traffic / alg,
         "rocprof_kernel_avg_us": float(krow["AverageNs"]) / 1e3, "rocprof_kernel_min_us": float(krow["MinNs"]) / 1e3,
         "rocprof_kernel_calls": int(krow["Calls"]), "profile": f"profiles/{rnd}_{workload}_*",
+        "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
+        "sq_pass_kernel_us": pass_duration_us(os.path.join(raw, "sq"), pat),
     }
     json.dump(allj, open(tj, "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc.txt"), "w") as fo:
@@ -60,6 +74,13 @@ def main():
         w = sq["SQ_WAVE_CYCLES"]
         per = waves * horizon
         fo.write(f"\n   per wave per env-step: VALU {sq['SQ_INSTS_VALU']/per:.1f}  SALU {sq['SQ_INSTS_SALU']/per:.1f}  LDS {sq['SQ_INSTS_LDS']/per:.2f} instructions; {4*w/per:.0f} cycles\n")
+        sq_us = pass_duration_us(os.path.join(raw, "sq"), pat)
+        if sq_us:
+            fo.write(f"   kernel duration INSIDE the SQ pass: {sq_us:.1f} us (stats pass: {float(krow['AverageNs'])/1e3:.1f}); "
+                     f"implied clock = 4 x SQ_WAVE_CYCLES / waves / duration = {4*w/waves/sq_us/1e3:.2f} GHz "
+                     f"(only meaningful when every wave is resident for the whole launch)\n")
+            fo.write(f"   VALU issue roofline: {sq['SQ_INSTS_VALU']:.4g} wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x {float(krow['AverageNs'])/1e3:.1f} us) = "
+                     f"{sq['SQ_INSTS_VALU']*4/(1024*2.4e9*float(krow['AverageNs'])*1e-9):.1%}\n")
         fo.write(f"   wave time split: issuing {sq['SQ_ACTIVE_INST_ANY']/w:.1%}  parked at s_waitcnt {sq['SQ_WAIT_ANY']/w:.1%}  issue stall {sq['SQ_WAIT_INST_ANY']/w:.1%}\n")
     print(open(os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc.txt")).read())
 
