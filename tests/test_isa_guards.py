@@ -140,3 +140,44 @@ def test_no_instruction_touches_an_lds_read_destination_before_its_wait(function
                 assert not (_vregs(o2) & dst), f"{name}: {m2} {o2} at {a2:#x} touches {sorted(dst)} of the ds_read_b128 at {a:#x}"
             checked += 1
     assert checked >= 40
+
+
+# ------------------------------------------------------------------------------------------------
+# hipcc bug found in round 2 (DESIGN.md §6, "the cheetah RK4 miscompile"): the register allocator may place VGPR
+# spill stores (v_accvgpr_write_b32 / scratch_store) at the top of a control-flow JOIN block, in front of the
+# `s_or_b64 exec, exec, s[..]` that restores EXEC.  When the skipped branch was empty the wave falls into the block with
+# EXEC = 0, the EXEC-masked spill stores write nothing, and the later reload reads stale registers.
+def exec_restore_hazards(ins):
+    """[(addr of the restore, [vector instructions in front of it])] for the shape
+           s_and_saveexec_b64 sX, cond ; s_cbranch_execnz COLD        (falls through with EXEC = 0 when no lane is in COLD)
+       JOIN:  <vector instructions>                                    <- execute with EXEC = 0 / COLD's lanes only
+              s_or_b64 exec, exec, sX"""
+    out = []
+    for k, (a, m, o) in enumerate(ins):
+        if not (m == "s_or_b64" and re.match(r"exec, exec, s\[\d+:\d+\]", o)):
+            continue
+        saved = o.split(",")[2].strip()
+        j, vec = k - 1, []
+        while j >= 0 and not ins[j][1].startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")) and "exec" not in ins[j][2].split(",")[0]:
+            if ins[j][1].startswith(("v_", "ds_", "global_", "scratch_", "buffer_", "flat_")) and ins[j][1] not in (
+                    "v_readlane_b32", "v_writelane_b32"):  # SGPR spill traffic ignores EXEC
+                vec.append((hex(ins[j][0]), ins[j][1], ins[j][2]))
+            j -= 1
+        if not vec or j < 1 or ins[j][1] != "s_cbranch_execnz":
+            continue
+        # the branch is fed by the saveexec that produced the mask this restore consumes
+        for q in range(j - 1, max(j - 4, -1), -1):
+            if ins[q][1] == "s_and_saveexec_b64" and ins[q][2].split(",")[0].strip() == saved:
+                out.append((hex(a), vec[::-1]))
+                break
+    return out
+
+
+def test_no_vector_instruction_in_front_of_an_exec_restore(functions):
+    """Every kernel of the shipped library: nothing EXEC-dependent sits between the start of a join block and its EXEC restore."""
+    bad = {}
+    for name, ins in functions.items():
+        h = exec_restore_hazards(ins)
+        if h:
+            bad[name] = h[:3]
+    assert not bad, bad

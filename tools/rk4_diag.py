@@ -42,3 +42,12 @@ for integ in ("euler", "rk4"):
             viol = (s0[:, 3:9] < lo) | (s0[:, 3:9] > hi)
             print("   limit violated at s0 [bth bsh bft fth fsh fft], among bad:", viol[bad].sum(axis=0).tolist(), " among good:", viol[~bad].sum(axis=0).tolist())
             print("   z (torso height offset) among bad: mean %.3f min %.3f; among good: mean %.3f" % (s0[bad, 1].mean(), s0[bad, 1].min(), s0[~bad, 1].mean()))
+
+# the stateless one-step kernel (body_next_obs_kernel<CheetahBody, true>): the same RK4 substep without the rollout scaffolding
+from emei_amd import engine as E  # noqa: E402
+
+o32 = torch.as_tensor(s0, dtype=torch.float32, device="cuda")
+nxt = E.batch_next_obs(name, o32, torch.as_tensor(act32, device="cuda"), dt, 1, "ref", "rk4").cpu().numpy()
+o_st = ostep(o32.double().cpu().numpy(), act32.astype(np.float64), 1, dt, O.opts("rk4"))[0]
+err = np.abs(nxt - o_st) / np.maximum(np.abs(o_st), 1.0)
+print(f"== next_obs rk4: max err {err.max():.3e}; bad (>1e-5) {(err.max(axis=1) > 1e-5).sum()} / {n}")
