@@ -43,13 +43,74 @@ __device__ __forceinline__ void sincos_r(T x, T& s, T& c) {
     sincos_repair_r(x, s, c);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Arguments beyond the fast path's range: exact reduction modulo 2 pi (Payne-Hanek on the hardware's 2/pi segments,
+// v_trig_preop_f64), so that the SAME table path serves every finite angle.  The device library's sincos() used to
+// repair such arguments after the fact; inlined, its ~160 instructions and 8 polynomial constants (16 VGPRs, hoisted
+// out of the rollout loop) sat in every kernel for a branch that no physical trajectory takes.  This reduction needs
+// five constants and returns an angle in [-4, 4] with an absolute error <= ~1e-15 (NaN for a non-finite argument).
+__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+__device__ __forceinline__ double trig_reduce_large(double x) {
+    const double ax = __builtin_fabs(x);
+    // three consecutive 53-bit pieces of 2/pi positioned for the exponent of x: the bits in front of p2 only contribute
+    // whole multiples of 4 quadrants to x * 2/pi.  Above 2^945 the hardware returns the pieces scaled by 2^128.
+    const double p2 = __builtin_amdgcn_trig_preop(ax, 0), p1 = __builtin_amdgcn_trig_preop(ax, 1),
+                 p0 = __builtin_amdgcn_trig_preop(ax, 2);
+    const double xs = ax >= 0x1.0p+945 ? __builtin_ldexp(ax, -128) : ax;
+    double f2h = p2 * xs;
+    const double f2l = __builtin_fma(p2, xs, -f2h);
+    const double f1h = p1 * xs, f1l = __builtin_fma(p1, xs, -f1h);
+    const double f0h = p0 * xs;
+    // y = x * 2/pi modulo 4 as an unevaluated sum: top term modulo 4 (exact), then two-sums
+    const double q = __builtin_ldexp(f2h, -2);
+    f2h = __builtin_ldexp(__builtin_amdgcn_fract(q), 2);
+    double s1, e1, s2, e2;
+    two_sum(f1h, f2l, s1, e1);
+    two_sum(f2h, s1, s2, e2);
+    const double low = ((f1l + f0h) + e1) + e2;
+    const double k = __builtin_rint(s2);
+    const double f = (s2 - k) + low;                       // |f| <= 1/2: the fraction of a quadrant
+    const double k4 = __builtin_fma(-4.0, __builtin_rint(k * 0.25), k);  // quadrant, centred: -2 .. 2
+    const double t = k4 + f;
+    const double r = __builtin_fma(t, 6.123233995736766e-17, t * 1.5707963267948966);
+    const double res = x < 0.0 ? -r : r;
+    return __builtin_isfinite(x) ? res : __builtin_nan("");
+}
+// the argument the table path sees: x itself in every practical case
+__device__ __forceinline__ double trig_arg(double x) {
+    if (__builtin_expect(!(__builtin_fabs(x) <= kFastTrigLimitF64), 0)) return trig_reduce_large(x);
+    return x;
+}
+
 // Trig context of the cart/pole kernels: float64 uses the 256-entry {sin,cos} table every kernel
 // stages in LDS (emei_math.h: fast_sincos_tab); float32 keeps the polynomial kernels.
 struct TrigCtx {
     const SinCosEntry* tab;  // LDS
+    // two polynomial coefficients kept in VGPRs for the whole kernel (sincos_begin_ctx): with both coefficients of an
+    // inner Horner step as literals hipcc emits v_mov_b64 + the two-address v_fmac_f64 per evaluation
+    double c3, c4;  // -1/6, 1/24
+    uint32_t lds_base;  // byte address of `tab` in LDS, wave-uniform (an SGPR)
 };
+__device__ __forceinline__ void trig_ctx_init(TrigCtx& t, const SinCosEntry* tab) {
+    t.tab = tab;
+    t.c3 = -1.0 / 6, t.c4 = 1.0 / 24;
+    asm volatile("" : "+v"(t.c3), "+v"(t.c4));  // opaque: not re-materialised at every use
+    uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)tab);
+    asm volatile("" : "+s"(base));  // opaque: as a literal the base costs the index a third instruction (v_or_b32)
+    t.lds_base = base;
+}
+// a * B + c with the constant B in scalar registers and c in vector registers: the three-address form
+__device__ __forceinline__ double fma_vsv(double a, double b_uniform, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
 __device__ __forceinline__ void sincos_fast_ctx(const TrigCtx& t, double x, double& s, double& c) {
-    fast_sincos_tab(x, t.tab, s, c);
+    fast_sincos_tab(x, t.tab, s, c);  // |x| <= kFastTrigLimitF64 (callers reduce first: sincos_ctx, sincos_begin_ctx)
 }
 __device__ __forceinline__ void sincos_fast_ctx(const TrigCtx&, float x, float& s, float& c) { fast_sincosf(x, s, c); }
 // Two-phase form for the substep: begin as soon as the new angle exists, end after the dynamics, so
@@ -68,7 +129,8 @@ struct TrigPendingF64 {
 struct TrigPendingF32 {
     float s, c;
 };
-__device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, double x) {
+__device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, double x_any) {
+    const double x = trig_arg(x_any);  // a cold branch in front of the straight-line block
     const double inv_step = 40.74366543152521;                                    // 256 / (2 pi)
     const double H1 = 1.5707963267948966 / 64, H2 = 6.123233995736766e-17 / 64;  // 2pi/256 = H1 + H2
     TrigPendingF64 p;
@@ -77,14 +139,14 @@ __device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, dou
     const double magic = 6755399441055744.0;
     const double shifted = __builtin_fma(x, inv_step, magic);
     const double n = shifted - magic;
-    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)t.tab +
-                          (((uint32_t)__double2loint(shifted) & (uint32_t)(kTrigTableSize - 1)) << 4);
+    // table index from the low mantissa bits: (k & 255) * 16 + base, two instructions (v_and_b32, v_lshl_add_u32)
+    const uint32_t addr = (((uint32_t)__double2loint(shifted) & (uint32_t)(kTrigTableSize - 1)) << 4) + t.lds_base;
     asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
     double r = __builtin_fma(-n, H1, x);
     r = __builtin_fma(-n, H2, r);
     const double z = r * r;
-    p.sr = __builtin_fma(r * z, __builtin_fma(z, 1.0 / 120, -1.0 / 6), r);
-    p.cr = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.0 / 720, 1.0 / 24), -0.5), 1.0);
+    p.sr = __builtin_fma(r * z, fma_vsv(z, 1.0 / 120, t.c3), r);
+    p.cr = __builtin_fma(z, __builtin_fma(z, fma_vsv(z, -1.0 / 720, t.c4), -0.5), 1.0);
     return p;
 }
 __device__ __forceinline__ void sincos_pin(const TrigPendingF64& p, double& a, double& b) {
@@ -103,22 +165,44 @@ __device__ __forceinline__ TrigPendingF32 sincos_begin_ctx(const TrigCtx&, float
 __device__ __forceinline__ void sincos_pin(const TrigPendingF32&, float&, float&) {}
 __device__ __forceinline__ void sincos_end_ctx(TrigPendingF32& p, float, float, float& s, float& c) { s = p.s, c = p.c; }
 
-template <typename T>
-__device__ __forceinline__ void sincos_ctx(const TrigCtx& t, T x, T& s, T& c) {
+__device__ __forceinline__ void sincos_ctx(const TrigCtx& t, double x, double& s, double& c) {
+    sincos_fast_ctx(t, trig_arg(x), s, c);
+}
+// after sincos_end_ctx: float32 still repairs out-of-range arguments after the fact; float64 reduced them up front
+__device__ __forceinline__ void sincos_post_ctx(double, double&, double&) {}
+__device__ __forceinline__ void sincos_post_ctx(float x, float& s, float& c) { sincos_repair_r(x, s, c); }
+__device__ __forceinline__ void sincos_ctx(const TrigCtx& t, float x, float& s, float& c) {
     sincos_fast_ctx(t, x, s, c);
     sincos_repair_r(x, s, c);
 }
 // every thread of the 256-thread block copies one entry; the barrier must be reached by ALL threads
 // (callers stage the table before any early return)
-__device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src) {
+// `scale`: an env whose dynamics only ever use m * sin and m * cos stages the table pre-multiplied (InvPend: the
+// pole's mass moment) and saves the two products per substep; 1 = the plain table.
+__device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src, double scale = 1.0) {
     static_assert(kBlock == kTrigTableSize, "one table entry per thread");
-    lds[threadIdx.x] = src[threadIdx.x];
+    SinCosEntry e = src[threadIdx.x];
+    if (scale != 1.0) e.s *= scale, e.c *= scale;
+    lds[threadIdx.x] = e;
     __syncthreads();
 }
 
 // hardware reciprocal seed + Newton (emei_math.h)
 __device__ __forceinline__ double rcp_r(double d) { return refine_rcp(d, __builtin_amdgcn_rcp(d)); }
 __device__ __forceinline__ float rcp_r(float d) { return 1.0f / d; }
+
+// hardware seed (measured 2^-24.4 relative, tools/rcp_accuracy.hip) + ONE Newton step: <= 2.2e-15 relative.  For the
+// MuJoCo-backed dynamics (kernel <-> oracle 1e-9); the reference-pinned CartPole keeps the two-step rcp_r.
+__device__ __forceinline__ double rcp1_r(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(r0, __builtin_fma(-d, r0, 1.0), r0);
+}
+__device__ __forceinline__ float rcp1_r(float d) { return 1.0f / d; }
+// v with the sign bit flipped where `mask` (0 or 0x80000000) says so: J * v for J = +-1 in one 32-bit instruction
+__device__ __forceinline__ double flip_sign(double v, uint32_t mask) {
+    return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v));
+}
+__device__ __forceinline__ float flip_sign(float v, uint32_t mask) { return __uint_as_float(__float_as_uint(v) ^ mask); }
 
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

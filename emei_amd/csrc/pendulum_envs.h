@@ -11,6 +11,7 @@
 //   init(s, seed, env, episode, p)   device-side reset
 // R is the arithmetic type: double (EMEI_PRECISION_REF) or float (EMEI_PRECISION_F32).
 #pragma once
+#include "constexpr_math.h"
 #include "emei_device.h"
 
 namespace emei {
@@ -43,6 +44,11 @@ struct CartPole {
         TrigCtx trig;
     };
     using Action = R;  // force / total_mass
+    __host__ __device__ static constexpr double trig_scale() { return 1.0; }
+    // BASELINE configs[1] / [4] give the staged rollout 1-2 waves per SIMD: registers are free, the spare initial state
+    // of the reset path lives in them
+    static constexpr bool kSpareInLds = false;
+    static constexpr int kMinWavesPerEU = 1;
     // only the float32 time step reaches the kernel: a small argument block leaves the scalar
     // registers to the polynomial constants of sincos (otherwise they are copied through VGPRs)
     struct Params {
@@ -102,7 +108,7 @@ struct CartPole {
         s[1] += (R)__fmul_rn((float)x_acc, p.dt32);
         s[3] += (R)__fmul_rn((float)theta_acc, p.dt32);
         sincos_end_ctx(pending, x_acc, theta_acc, c.sn, c.cs);
-        sincos_repair_r(s[2], c.sn, c.cs);  // |theta| > 1e6 only; after the straight-line block
+        sincos_post_ctx(s[2], c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
@@ -152,77 +158,143 @@ struct CartPole {
 // Dynamics: MuJoCo's 2-DoF model in closed form + emei's forward-Euler position override
 // (mujoco_env.py:91-97,169-195).  Parity with libmujoco is unpinned.
 // =============================================================================================
+// Model constants from assets/inverted_pendulum.xml (gravity :8; slider range :14; cart capsule :15; hinge :17; pole
+// capsule :18; motor :23), capsule mass / inertia by MuJoCo's inertiafromgeom forms — evaluated at COMPILE time
+// (constexpr_math.h): as kernel arguments the 25 doubles of PendParams + the sincos constants + the pointers exceeded
+// the SGPR file (154 spilled SGPRs = v_readlane / v_writelane VECTOR instructions in the rollout loop; round 1).  Only
+// what depends on the run-time dt travels as an argument.  oracle/emei_oracle.c:emei_oracle_ip_model derives the same
+// numbers with libm; abi.hip:pend_params is the host twin used by the Body path.
+struct IpModel {
+    double M11, M22, M11M22, mpr, inv_mpr, gravity, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
+    double phi_off, sin_off, cos_off;  // phi = theta + phi_off is the angle of the pole's com from +z
+    double invw, dmin, dmax, inv_width;
+};
+constexpr IpModel ip_make_model(bool swingup) {
+    IpModel m{};
+    const double rho = 1000.0, pi = ce::kPi;
+    const auto capsule_mass = [&](double r, double half) { return rho * (pi * r * r * 2 * half + 4.0 / 3.0 * pi * r * r * r); };
+    const auto capsule_inertia_perp = [&](double r, double half) {
+        const double h = 2 * half, mcyl = rho * pi * r * r * h, msph = rho * 4.0 / 3.0 * pi * r * r * r;
+        return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
+    };
+    const double mc = capsule_mass(0.1, 0.1);
+    const double fx = 0.001, fz = 0.6, len = ce::sqrt(fx * fx + fz * fz);
+    const double mp = capsule_mass(0.049, len / 2), Icom = capsule_inertia_perp(0.049, len / 2), r = len / 2;
+    const double phi0 = ce::atan_small(fx, fz);
+    m.M11 = mc + mp, m.M22 = Icom + mp * r * r, m.M11M22 = m.M11 * m.M22;
+    m.mpr = mp * r, m.inv_mpr = 1.0 / m.mpr, m.gravity = 9.81;
+    m.gear = 100.0, m.ctrl_lo = -3.0, m.ctrl_hi = 3.0, m.x_lo = -2.0, m.x_hi = 2.0;
+    m.phi_off = phi0 + (swingup ? pi : 0.0);  // _update_model: pole body turned by pi about y (:135-137)
+    m.sin_off = ce::sin(m.phi_off), m.cos_off = ce::cos(m.phi_off);
+    const double M12 = m.mpr * ce::cos(phi0);
+    m.invw = m.M22 / (m.M11 * m.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
+    m.dmin = 0.9, m.dmax = 0.95, m.inv_width = 1.0 / 0.001;  // default solimp (.9 .95 .001)
+    return m;
+}
+__device__ constexpr IpModel kIpUpright = ip_make_model(false), kIpHanging = ip_make_model(true);
+
 template <int VARIANT, typename R>
 struct InvPend {
     using real = R;
     static constexpr bool kDiscrete = false;
     static constexpr int kActDim = 1;
+    static constexpr bool kF64 = sizeof(R) == 8;
+    // BASELINE configs[2]: 262 144 envs = 4 waves per SIMD, which only fit with <= 128 registers per lane (and <= 40 KiB
+    // of LDS per block): the spare initial state of the reset path goes to LDS, the rollout is compiled for 4 waves
+    static constexpr bool kSpareInLds = true;
+    static constexpr int kMinWavesPerEU = 4;
+    __device__ static constexpr const IpModel& km() { return VARIANT >= 2 ? kIpHanging : kIpUpright; }
+    // The dynamics only use mpr * sin(phi) and mpr * cos(phi): the float64 kernels stage the {sin,cos} table
+    // pre-multiplied by the pole's mass moment (emei_device.h:stage_trig_table), the carry holds the products
+    __host__ __device__ static constexpr double trig_scale() { return kF64 ? ip_make_model(VARIANT >= 2).mpr : 1.0; }
     struct Carry {
-        R sn, cs;  // of phi = theta + phi_off
+        R sn, cs;  // mpr * sin(phi), mpr * cos(phi), phi = theta + phi_off
         TrigCtx trig;
     };
-    using Action = R;  // clipped ctrl
-    using Params = PendParams;
-    static Params make_params(const PendParams& p) { return p; }
+    using Action = R;  // gear * clipped ctrl
+    struct Params {
+        double dt, limK, limB;  // time step; solref stiffness / damping of the slider limit (refsafe'd: depend on dt)
+        float init_sigma[4];
+        int32_t noise_shared;
+    };
+    static Params make_params(const PendParams& p) {
+        Params q;
+        q.dt = p.dt, q.limK = p.limK, q.limB = p.limB, q.noise_shared = p.noise_shared;
+        for (int i = 0; i < 4; ++i) q.init_sigma[i] = p.init_sigma[i];
+        return q;
+    }
 
     using RawAction = float;
     __device__ __forceinline__ static RawAction load_raw(const void* p, int dtype, int64_t idx) {
         return (dtype == EMEI_ACT_F32) ? ((const float*)p)[idx] : (float)load_discrete_action(p, dtype, idx);
     }
-    __device__ __forceinline__ static Action decode(RawAction a) { return (R)a; }
+    // ctrllimited motor (xml:23): the actuator force is constant over the substeps of a step.  The clamp runs in
+    // float32 (the bounds are exact there): one v_med3_f32
+    __device__ __forceinline__ static Action decode(RawAction a) {
+        const float u = __builtin_fminf(__builtin_fmaxf(a, (float)km().ctrl_lo), (float)km().ctrl_hi);
+        return (R)km().gear * (R)u;
+    }
     template <typename T>
     __device__ __forceinline__ static Action decode_t(T a) {
-        return (R)a;
+        return decode((float)a);
     }
     __device__ __forceinline__ static Action load_action(const void* p, int dtype, int64_t idx) {
         return decode(load_raw(p, dtype, idx));
     }
 
-    __device__ __forceinline__ static void prime(const R s[4], Carry& c, const PendParams& p) {
-        sincos_ctx(c.trig, s[1] + (R)p.phi_off, c.sn, c.cs);
+    __device__ __forceinline__ static void prime(const R s[4], Carry& c, const Params&) {
+        sincos_ctx(c.trig, s[1] + (R)km().phi_off, c.sn, c.cs);
+        if (!kF64) c.sn *= (R)km().mpr, c.cs *= (R)km().mpr;
     }
 
-    __device__ __forceinline__ static void substep(R s[4], Carry& c, R u, const PendParams& p) {
-        const R M11 = (R)p.M11, M22 = (R)p.M22;
+    // One substep.  P = mpr sin(phi), Q = mpr cos(phi) (= M12) at the OLD angle, gu = gear * ctrl:
+    //   f1 = gu + P omega^2,  f2 = g P,  det = M11 M22 - Q^2
+    //   a0 = (M22 f1 - Q f2) / det,  a1 = (M11 f2 - Q f1) / det        (+ the soft slider-limit force)
+    //   x += dt v_old, theta += dt omega_old (get_euler_pos, mujoco_env.py:189-191);  v += dt a0, omega += dt a1
+    __device__ __forceinline__ static void substep(R s[4], Carry& c, R gu, const Params& p) {
+        constexpr IpModel m = ip_make_model(VARIANT >= 2);
         const R dt = (R)p.dt;
-        // the new angle needs only the OLD angular velocity (get_euler_pos, mujoco_env.py:189-191), so its
-        // sin/cos is started first and lands under the dynamics (see CartPole::substep)
+        // the new angle needs only the OLD angular velocity, so its sin/cos is started first and lands under the dynamics
         const R x_old = s[0], v_old = s[2], om_old = s[3];
         s[0] = fma_r(dt, v_old, x_old);
         s[1] = fma_r(dt, om_old, s[1]);
-        R sn = c.sn, cs = c.cs;
-        auto pending = sincos_begin_ctx(c.trig, s[1] + (R)p.phi_off);
-        sincos_pin(pending, sn, cs);
-        R M12 = (R)p.mpr * cs;
-        R ctrl = u < (R)p.ctrl_lo ? (R)p.ctrl_lo : (u > (R)p.ctrl_hi ? (R)p.ctrl_hi : u);  // ctrllimited
-        R f1 = (R)p.gear * ctrl + (R)p.mpr * sn * om_old * om_old;
-        R f2 = (R)p.mgr * sn;
-        R det = fma_r(-M12, M12, M11 * M22);
-        R idet = rcp_r(det);
-        R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
-        R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
-        // soft slider-limit constraint (MuJoCo joint limit, default solref/solimp)
-        // x_lo < x_hi: at most one side is violated, the smaller of the two distances is it (branch-free pick)
-        const R dlo = x_old - (R)p.x_lo, dhi = (R)p.x_hi - x_old;
-        const bool lower = dlo < dhi;
-        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
+        R P = c.sn, Q = c.cs;
+        auto pending = sincos_begin_ctx(c.trig, s[1] + (R)m.phi_off);
+        sincos_pin(pending, P, Q);
+        const R f1 = fma_r(P, om_old * om_old, gu);
+        const R gP = (R)m.gravity * P;  // f2
+        const R idet = rcp1_r(fma_r(-Q, Q, (R)m.M11M22));
+        R a0 = fma_r((R)m.M22, f1, -(Q * gP)) * idet;
+        R a1 = fma_r((R)m.M11, gP, -(Q * f1)) * idet;
+        // Soft slider-limit constraint (MuJoCo joint limit, default solref / solimp).  The rail is symmetric (xml:14,
+        // range -2 2): the violated side, if any, is the one x is on, and its distance is x_hi - |x|.
+        static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
+        const R dist = (R)m.x_hi - fabs(x_old);
         if (dist < R(0)) {
-            R xx = div_r(fabs(dist), (R)p.width);
-            R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
-            R imp = (R)p.dmin + y * ((R)p.dmax - (R)p.dmin);
-            R aref = -(R)p.limB * (J * v_old) - (R)p.limK * imp * dist;  // solref stiffness / damping, host constants
-            R A = M22 * idet;
-            R Rr = div_r(R(1) - imp, imp) * (R)p.invw;
-            R force = div_r(aref - J * a0, A + Rr);
+            const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one
+            const R A = (R)m.M22 * idet;                           // J M^-1 J^T
+            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every lane of the wave, almost always)
+            R imp = (R)m.dmax;
+            const R xx = -dist * (R)m.inv_width;
+            if (__builtin_expect(__ballot(xx < R(1)) != 0ull, 0)) {
+                const R u1 = R(1) - xx;
+                const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
+                imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+            }
+            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw)
+            const R aref = fma_r(-(R)p.limK * imp, dist, -(R)p.limB * flip_sign(v_old, jm));
+            const R force = (aref - flip_sign(a0, jm)) * imp * rcp1_r(fma_r(A, imp, (R(1) - imp) * (R)m.invw));
             if (force > R(0)) {
-                a0 += (M22 * idet) * J * force;
-                a1 += (-M12 * idet) * J * force;
+                const R Jf = flip_sign(force, jm);
+                a0 = fma_r(A, Jf, a0);
+                a1 = fma_r(-(Q * idet), Jf, a1);
             }
         }
-        s[2] = fma_r(dt, a0, v_old);   // MuJoCo Euler on qvel (no joint damping in this model)
+        s[2] = fma_r(dt, a0, v_old);  // MuJoCo Euler on qvel (no joint damping in this model)
         s[3] = fma_r(dt, a1, om_old);
         sincos_end_ctx(pending, a0, a1, c.sn, c.cs);
-        sincos_repair_r(s[1] + (R)p.phi_off, c.sn, c.cs);
+        if (!kF64) c.sn *= (R)m.mpr, c.cs *= (R)m.mpr;
+        sincos_post_ctx(s[1] + (R)m.phi_off, c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
@@ -232,17 +304,17 @@ struct InvPend {
         o[2] = s[2], o[3] = s[3];
     }
 
-    // cos(theta) from the carry of phi = theta + off
-    __device__ __forceinline__ static R cos_theta(const Carry& c, const PendParams& p) {
-        return c.cs * (R)p.cos_off + c.sn * (R)p.sin_off;
+    // cos(theta) from the carry of phi = theta + off (the carry is scaled by mpr)
+    __device__ __forceinline__ static R cos_theta(const Carry& c, const Params&) {
+        return c.cs * (R)(km().cos_off * km().inv_mpr) + c.sn * (R)(km().sin_off * km().inv_mpr);
     }
-    __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const PendParams& p) {
+    __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const Params& p) {
         if (VARIANT >= 2) return (R(1) - cos_theta(c, p)) / R(2);  // inverted_pendulum.py:139-142,174-177
         return R(1);                                                // :73-74,103-104
     }
-    __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const PendParams& p) {
+    __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const Params& p) {
         bool fin = finite_r(o[0]) & finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
-        bool inx = ((R)p.x_lo < o[0]) & (o[0] < (R)p.x_hi);
+        bool inx = ((R)km().x_lo < o[0]) & (o[0] < (R)km().x_hi);
         R y = cos_theta(c, p);
         bool notdone;
         if (VARIANT == 0) notdone = (y >= R(0.9)) & fin;           // :76-79
@@ -252,9 +324,9 @@ struct InvPend {
         return !notdone;
     }
 
-    __device__ __forceinline__ static void step(R s[4], Carry& c, Action u, const PendParams& p, int freq_rate,
+    __device__ __forceinline__ static void step(R s[4], Carry& c, Action gu, const Params& p, int freq_rate,
                                                 R o[4], R& rew, bool& term) {
-        for (int k = 0; k < freq_rate; ++k) substep(s, c, u, p);  // mujoco_env.py:88-97
+        for (int k = 0; k < freq_rate; ++k) substep(s, c, gu, p);  // mujoco_env.py:88-97
         obs_of(s, o);
         rew = reward(o, c, p);
         term = terminal(o, c, p);
@@ -263,18 +335,18 @@ struct InvPend {
     // device reset: init_qpos/qvel (zeros) + sigma * N(0,1) (mujoco_env.py:137-140); same draws as
     // body_kernels.h:gauss_state so both rollout paths of this env reset identically
     __device__ __forceinline__ static void init(R s[4], uint64_t seed, uint64_t env, uint32_t episode,
-                                                const PendParams& p) {
+                                                const Params& p) {
         u32x4 r = philox4x32_10(seed, env, episode, 0);
         float z[4];
         boxmuller(r.v[0], r.v[1], z[0], z[1]);
         boxmuller(r.v[2], r.v[3], z[2], z[3]);
-        if (p.noise_shared) {
-            s[0] = s[1] = (R)__fmul_rn(p.init_sigma[0], z[0]);
-            s[2] = s[3] = (R)__fmul_rn(p.init_sigma[2], z[1]);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] = (R)__fmul_rn(p.init_sigma[i], z[i]);
+        // selects, not branches: stores to s[] behind a branch end up behind a pointer phi and s[] on the stack (scratch)
+        const bool sh = p.noise_shared != 0;
+        const float v0 = __fmul_rn(p.init_sigma[0], z[0]);
+        const float v1 = sh ? v0 : __fmul_rn(p.init_sigma[1], z[1]);
+        const float v2 = __fmul_rn(p.init_sigma[2], sh ? z[1] : z[2]);
+        const float v3 = sh ? v2 : __fmul_rn(p.init_sigma[3], z[3]);
+        s[0] = (R)v0, s[1] = (R)v1, s[2] = (R)v2, s[3] = (R)v3;
     }
 };
 

@@ -39,7 +39,7 @@ template <class Env, typename ActT, bool FULL>
 __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<Env> a) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, a.trig);
+    stage_trig_table(trig_s, a.trig, Env::trig_scale());
     const ActT* __restrict__ actions = (const ActT*)a.actions;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
     int32_t steps = a.steps[i];
     uint32_t episode = a.episode[i];
     typename Env::Carry c;
-    c.trig.tab = trig_s;
+    trig_ctx_init(c.trig, trig_s);
     Env::prime(s, c, a.p);
 
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
@@ -138,20 +138,31 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 // => 1.31 vector stores + 1/16 loads per env-step instead of 3 stores + 1 load, and no 64 B
 // partial-line byte stores.  LDS slices are wave-private (LDS operations of one wave execute in
 // order), so there is no barrier anywhere.
-constexpr int kStage = 16;
-constexpr int kTileWaitKeep = kStage;  // VMEM operations left in flight when a staged action tile is retired
+// steps per staged tile: 16 for one-byte actions (1 KiB of LDS per wave and buffer); 8 for 4- and 8-byte actions, so that
+// the double-buffered tiles of a 256-thread block stay at 16 / 32 KiB and four blocks (with the other slices) fit a CU's
+// 160 KiB: config 3 runs 4 waves per SIMD
+template <typename ActT>
+constexpr int stage_steps() { return sizeof(ActT) == 1 ? 16 : 8; }
 
 template <class Env, typename ActT, bool FREQ1>
-__global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env::kMinWavesPerEU)))
+    pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
     using R = typename Env::real;
     constexpr int kWavesPerBlock = kBlock / kWave;
-    constexpr int kActVec = sizeof(ActT);  // 16-byte vectors per lane for a 16x64 tile of ActT
+    constexpr int kStage = stage_steps<ActT>();
+    constexpr int kTileWaitKeep = kStage;  // VMEM operations left in flight when a staged action tile is retired
+    constexpr int kActVec = kStage * sizeof(ActT) / 16;  // 1 KiB wave-loads (16 B per lane) per kStage x 64 tile of ActT
+    static_assert(kStage % 4 == 0 && kStage * kWave * sizeof(ActT) % 1024 == 0, "whole wave-loads, whole reward groups");
     __shared__ uint4 act_s[kWavesPerBlock][2][kStage * kWave * sizeof(ActT) / 16];
     __shared__ float rew_s[kWavesPerBlock][4][kWave];
     __shared__ uint8_t done_s[kWavesPerBlock][kStage][kWave];
+    // spare initial states (see maybe_reset): in LDS for the envs that run several waves per SIMD (registers are their
+    // occupancy limit), in registers otherwise
+    constexpr bool kLdsSpare = Env::kSpareInLds;
+    __shared__ R spare_s[kLdsSpare ? kWavesPerBlock : 1][6][kLdsSpare ? kWave : 1];
 
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, a.trig);
+    stage_trig_table(trig_s, a.trig, Env::trig_scale());
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
     if (i >= a.n) return;
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     int32_t steps = a.steps[i];
     uint32_t episode = a.episode[i];
     typename Env::Carry c;
-    c.trig.tab = trig_s;
+    trig_ctx_init(c.trig, trig_s);
     Env::prime(s, c, a.p);
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
     const int last = a.n_steps - 1;
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
     // episode: a reset just copies it, and spares are re-drawn only when a resetting lane has none —
     // then for every lane without one at once (the first reset of a wave draws all 64).  The draw is a
     // pure function of (seed, global env, episode), so results do not depend on when it is computed.
-    R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);
+    R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);  // dead outside the redraw when the spare lives in LDS
     bool have_spare = false;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         // cold: laid out of line so that the usual case falls through
@@ -219,19 +230,29 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
             if (__ballot((done != 0) & !have_spare) != 0ull) {
                 if (!have_spare) {
                     typename Env::Carry sc;
-                    sc.trig.tab = trig_s;
+                    sc.trig = c.trig;
                     Env::init(sp, a.seed, a.env_offset + (uint64_t)i, episode + 1u, a.p);
                     Env::prime(sp, sc, a.p);
-                    sp_sn = sc.sn, sp_cs = sc.cs;
+                    if constexpr (kLdsSpare) {
+                        spare_s[wv][0][lane] = sp[0], spare_s[wv][1][lane] = sp[1], spare_s[wv][2][lane] = sp[2];
+                        spare_s[wv][3][lane] = sp[3], spare_s[wv][4][lane] = sc.sn, spare_s[wv][5][lane] = sc.cs;
+                    } else {
+                        sp_sn = sc.sn, sp_cs = sc.cs;
+                    }
                     have_spare = true;
                 }
             }
             if (done != 0) {
                 ++episode;
                 steps = 0;
+                if constexpr (kLdsSpare) {  // a lane only ever reads what it wrote itself: no fence
+                    s[0] = spare_s[wv][0][lane], s[1] = spare_s[wv][1][lane], s[2] = spare_s[wv][2][lane];
+                    s[3] = spare_s[wv][3][lane], c.sn = spare_s[wv][4][lane], c.cs = spare_s[wv][5][lane];
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s[k] = sp[k];
-                c.sn = sp_sn, c.cs = sp_cs;
+                    for (int k = 0; k < 4; ++k) s[k] = sp[k];
+                    c.sn = sp_sn, c.cs = sp_cs;
+                }
                 have_spare = false;
             }
         }
@@ -244,7 +265,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
         *(float4*)(a.reward_out + row0 * n + rew_lane_off) = v;
     };
     auto store_done_rows = [&](int64_t row0, const uint4& v) __attribute__((always_inline)) {
-        *(uint4*)(a.done_out + row0 * n + done_lane_off) = v;
+        if (kStage == 16 || lane < 4 * kStage) *(uint4*)(a.done_out + row0 * n + done_lane_off) = v;  // kStage rows x 64 B
     };
 
     EMEI_LOAD_TILE(0, 0)
@@ -284,7 +305,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
                 if (q == 3) {
                     wave_lds_fence();  // the flush reads what OTHER lanes staged
                     rew_pend = ((const float4*)&rew_s[wv][0][0])[lane];                             // 4 rows x 256 B
-                    if (g == kStage / 4 - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane];  // 16 rows x 64 B
+                    if (g == kStage / 4 - 1) done_pend = ((const uint4*)&done_s[wv][0][0])[lane & (4 * kStage - 1)];  // kStage rows x 64 B
                     wave_lds_fence();  // ... and is done before the next group overwrites the slice
                 }
                 maybe_reset();
@@ -292,7 +313,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
         }
         // Retire the tile.  Loads, stores and LDS-DMA share one in-order counter, and the tile's loads were
         // issued before ALL of this tile's stores, of which the kStage observation stores are unconditional
-        // (the reward / done flushes add 3 to 5 more): leaving the kTileWaitKeep = kStage youngest operations
+        // (the reward / done flushes add 1 to 5 more): leaving the kTileWaitKeep = kStage youngest operations
         // in flight therefore covers every LDS-DMA load, and what it additionally waits for was issued at
         // least kStage - 3 steps ago.  The count is DERIVED from the tile constants — a hand-written 19
         // (16 + the first tile's 3 reward flushes) was exact with zero margin — and tests/test_isa_guards.py
@@ -304,7 +325,7 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_staged_kernel(const Rollo
         store_rew_rows(t0 - 4, rew_pend);
         store_done_rows(t0 - kStage, done_pend);
     }
-    // tail (< 16 steps): direct loads and stores
+    // tail (< kStage steps): direct loads and stores
     for (int t = t0; t < a.n_steps; ++t) {
         R o[4], rew;
         advance((actions + (int64_t)t * n)[li], o, rew);
@@ -378,7 +399,7 @@ __global__ void __launch_bounds__(kBlock)
                                 typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, trig);
+    stage_trig_table(trig_s, trig, Env::trig_scale());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 v = obs[i];
@@ -386,7 +407,7 @@ __global__ void __launch_bounds__(kBlock)
     // the observation IS the state for reward/terminal purposes (wrapped angle has the same cosine);
     // build the carry from it.  For InvertedPendulum o[1] is theta, prime() adds phi_off itself.
     typename Env::Carry c;
-    c.trig.tab = trig_s;
+    trig_ctx_init(c.trig, trig_s);
     Env::prime(o, c, p);
     if (reward) reward[i] = (float)Env::reward(o, c, p);
     if (terminal) terminal[i] = (uint8_t)Env::terminal(o, c, p);
@@ -399,14 +420,14 @@ __global__ void __launch_bounds__(kBlock)
                          int freq_rate, typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, trig);
+    stage_trig_table(trig_s, trig, Env::trig_scale());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 v = obs[i];
     R s[4] = {(R)v.x, (R)v.y, (R)v.z, (R)v.w}, o[4], rew;
     bool term;
     typename Env::Carry c;
-    c.trig.tab = trig_s;
+    trig_ctx_init(c.trig, trig_s);
     Env::prime(s, c, p);
     Env::step(s, c, Env::load_action(actions, action_dtype, i), p, freq_rate, o, rew, term);
     next_obs[i] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
@@ -418,7 +439,7 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; 
 template <class Env, typename ActT>
 static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
     const bool full = a.obs_out && a.reward_out && a.done_out;
-    if (full && a.n_steps >= kStage && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
+    if (full && a.n_steps >= stage_steps<ActT>() && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
         aligned16(a.reward_out) && aligned16(a.done_out))
     {
         if (a.freq_rate == 1) {

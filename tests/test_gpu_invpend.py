@@ -152,3 +152,44 @@ def test_full_size_config3_properties():
     th = obs[..., 1]
     assert float(th.min()) >= -np.pi - 1e-6 and float(th.max()) < np.pi + 1e-6
     assert float(rew.min()) >= 0 and float(rew.max()) <= 1 and bool(torch.isfinite(obs).all())
+
+
+def test_huge_and_nonfinite_angles():
+    """Angles beyond the table path's range (|theta| > 1e6 rad) go through the exact modulo-2-pi reduction
+    (emei_device.h:trig_reduce_large, v_trig_preop_f64); non-finite angles give NaN.  The oracle's libm is exact for any
+    argument, so the velocities of one substep (which carry sin / cos of the OLD angle) pin the reduction."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(7)
+    mags = np.array([1.0000001e6, 3.3e6, 1e7, 7.7e8, 1e10, 2.5e12, 1e15, 4e18, 1e30, 1e100, 8.8e200, 1.7e308])
+    theta = np.concatenate([mags, -mags, mags * rng.uniform(0.5, 1.0, len(mags)), rng.uniform(-1e9, 1e9, 476)])
+    n = len(theta)
+    s0 = np.column_stack([rng.uniform(-1.5, 1.5, n), theta, rng.normal(0, 1, n), np.zeros(n)])  # omega 0: theta stays put
+    act = rng.uniform(-3, 3, n).astype(np.float32)
+    for name, variant in (("BoundaryInvertedPendulumSwingUp", "boundary_swingup"), ("ReboundInvertedPendulumBalancing", "rebound_balancing")):
+        eng = _engine(name, n, freq_rate=1, real_time_scale=0.02)
+        eng.set_state(s0)
+        obs, rew, done = eng.step(torch.as_tensor(act, device=eng.device))
+        o_st, o_obs, o_rew, o_term = O.ip_step(variant, s0, act.astype(np.float64), 1, 0.02)
+        st = eng.get_state().cpu().numpy()
+        # v, omega carry sin / cos of the huge angle.  The oracle adds the offsets as (theta + phi0) + pi, the kernel as
+        # theta + (phi0 + pi): the two sums may differ by one ulp of theta, i.e. by dt * |da/dphi| * ulp(theta) <= ulp(theta)
+        err = np.abs(st[:, [0, 2, 3]] - o_st[:, [0, 2, 3]]).max(axis=1)
+        assert np.all(err <= 1e-9 + 2 * np.spacing(np.abs(theta))), float((err - 2 * np.spacing(np.abs(theta))).max())
+    # CartPole (pinned to the reference): the same reduction behind math.sin / math.cos of the reference
+    sc = np.column_stack([rng.uniform(-1, 1, n), rng.normal(0, 1, n), theta, np.zeros(n)])
+    a = rng.integers(2, size=n)
+    eng = _engine("CartPoleSwingUp", n)
+    eng.set_state(sc)
+    obs, rew, done = eng.step(torch.as_tensor(a, device=eng.device).to(torch.uint8))
+    nxt, orew, oterm = O.cartpole_step("swingup", sc, a)
+    # the derivative is rounded to float32 before it is accumulated (cartpole.py:60): a last-bit difference of sin / cos
+    # may flip that rounding (6e-8 relative of an acceleration of O(10), times dt)
+    assert rel_err(eng.get_state().cpu().numpy()[:, [0, 1, 3]], nxt[:, [0, 1, 3]], floor=1.0) <= 5e-8
+    assert rel_err(rew.cpu().numpy(), orew) <= 1e-6
+    # non-finite angles: NaN out, terminal (inverted_pendulum.py:179-183: not finite -> done)
+    bad = np.array([[0.0, np.inf, 0.0, 0.0], [0.0, -np.inf, 0.0, 0.0], [0.0, np.nan, 0.0, 0.0]])
+    eng = _engine("BoundaryInvertedPendulumSwingUp", 3)
+    eng.set_state(bad)
+    obs, rew, done = eng.step(torch.zeros(3, dtype=torch.float32, device=eng.device))
+    assert bool(torch.isnan(obs[:, 2:]).all()) and bool((done & 1).all())

@@ -4,7 +4,7 @@ kernels rest on (cdna_hip_programming.md §5.7 items 1 and 4: hipcc neither coun
 
 For every `pend_rollout_staged_kernel` instantiation:
   * no scratch traffic and no AGPR moves (the kernel's register budget is what DESIGN.md says it is);
-  * the tile-retire wait is `s_waitcnt vmcnt(kStage)` and the tile loop it closes carries at least one
+  * the tile-retire wait is `s_waitcnt vmcnt(kStage)` (kStage = 16 steps for one-byte actions, 8 otherwise) and the tile loop it closes carries at least one
     16-byte store per unrolled step (pendulum_kernels.h: kTileWaitKeep is derived from those stores);
   * no instruction touches the destination registers of an LDS read (`ds_read_b128`: the {sin,cos} table entry
     of emei_device.h:sincos_begin_ctx and the staged flushes) before a wait on lgkmcnt — a compiler copy or spill
@@ -20,7 +20,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "emei_amd", "libemei_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-K_STAGE = 16  # pendulum_kernels.h: kStage == kTileWaitKeep
+def k_stage(name):
+    """pendulum_kernels.h:stage_steps<ActT>() == kTileWaitKeep: 16 steps per tile for one-byte actions (mangled 'h'), 8 otherwise"""
+    act = re.search(r"E([hilf])Lb[01]EEEv", name).group(1)
+    return 16 if act == "h" else 8
 
 pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
 
@@ -108,7 +111,7 @@ def test_tile_retire_wait_is_derived_from_the_obs_stores(functions):
                    if m == "s_waitcnt" and re.fullmatch(r"vmcnt\((\d+)\)", o)]
         # the hand-written retire wait is the only counted wait that leaves >= 8 operations in flight
         retire = [(k, n) for k, n in counted if n >= 8]
-        assert len(retire) == 1 and retire[0][1] == K_STAGE, (name, counted)
+        assert len(retire) == 1 and retire[0][1] == k_stage(name), (name, counted)
         loop = _loop_through(ins, retire[0][0])
         assert loop, name  # the wait closes a loop (the tile loop)
         loads = [k for k in loop if ins[k][1] == "global_load_lds_dwordx4"]
