@@ -273,7 +273,8 @@ struct InvPend {
         if (dist < R(0)) {
             const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one
             const R A = (R)m.M22 * idet;                           // J M^-1 J^T
-            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every lane of the wave, almost always)
+            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost
+            // always — then the wave skips the polynomial)
             R imp = (R)m.dmax;
             const R xx = -dist * (R)m.inv_width;
             if (__builtin_expect(__ballot(xx < R(1)) != 0ull, 0)) {
@@ -281,7 +282,7 @@ struct InvPend {
                 const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
                 imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
             }
-            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw)
+            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw): one division
             const R aref = fma_r(-(R)p.limK * imp, dist, -(R)p.limB * flip_sign(v_old, jm));
             const R force = (aref - flip_sign(a0, jm)) * imp * rcp1_r(fma_r(A, imp, (R(1) - imp) * (R)m.invw));
             if (force > R(0)) {

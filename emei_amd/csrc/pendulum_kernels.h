@@ -223,10 +223,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     // then for every lane without one at once (the first reset of a wave draws all 64).  The draw is a
     // pure function of (seed, global env, episode), so results do not depend on when it is computed.
     R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);  // dead outside the redraw when the spare lives in LDS
+    const unsigned long long reset_mask = auto_reset ? ~0ull : 0ull;
     bool have_spare = false;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         // cold: laid out of line so that the usual case falls through
-        if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
+        if (__builtin_expect((__ballot(done != 0) & reset_mask) != 0ull, 0)) {  // scalar test: no vector instruction
             if (__ballot((done != 0) & !have_spare) != 0ull) {
                 if (!have_spare) {
                     typename Env::Carry sc;
