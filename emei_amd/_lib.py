@@ -39,6 +39,8 @@ KERNEL_PEND_STAGED_FREQ1, KERNEL_PEND_STAGED, KERNEL_PEND_GENERIC_FULL, KERNEL_P
 # enum emei_integrator (mujoco_env.py:70-79) / enum emei_noise_layout
 INTEGRATORS = {"euler": 0, "semi_implicit_euler": 1, "rk4": 2}
 NOISE_IID, NOISE_SHARED = 0, 1
+# enum emei_solver
+SOLVERS = {"newton": 0, "sweep1": 1}
 CONFIG_SIZE_V1 = 64
 MAX_STATE_DIM = 32
 MAX_ENV_PARAMS = 8
@@ -69,7 +71,7 @@ class EmeiConfig(C.Structure):
         ("obs_sigma", C.c_float * MAX_STATE_DIM),
         # struct_size 400: constructor parameters of the reward / terminal functions
         ("env_param_mask", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("solver", C.c_uint32),
         ("env_params", C.c_double * MAX_ENV_PARAMS),
     ]
 

@@ -186,6 +186,7 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i)
         if (!(cfg->init_sigma[i] >= 0) || !(cfg->obs_sigma[i] >= 0))
             return fail(EMEI_ERR_INVALID, "emei_create: noise sigmas must be >= 0");
+    if (cfg->solver != EMEI_SOLVER_NEWTON && cfg->solver != EMEI_SOLVER_SWEEP1) return fail(EMEI_ERR_INVALID, "emei_create: solver=%u", cfg->solver);
     if (cfg->env_param_mask >> EMEI_MAX_ENV_PARAMS) return fail(EMEI_ERR_INVALID, "emei_create: env_param_mask=0x%x", cfg->env_param_mask);
     if (cfg->env_param_mask != 0 && cfg->env_id != EMEI_HALFCHEETAH_RUNNING && cfg->env_id != EMEI_HOPPER_RUNNING)
         return fail(EMEI_ERR_UNSUPPORTED, "emei_create: env_id %d takes no reward / health parameters", cfg->env_id);
@@ -304,6 +305,7 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     L.env_offset = h->cfg.env_index_offset;
     L.dt = h->cfg.real_time_scale;
     L.integrator = h->cfg.integrator;
+    L.solver = (int)h->cfg.solver;
     memcpy(L.noise.init, h->cfg.init_sigma, sizeof(L.noise.init));
     memcpy(L.noise.obs, h->cfg.obs_sigma, sizeof(L.noise.obs));
     L.noise.shared = h->cfg.noise_layout == EMEI_NOISE_SHARED;

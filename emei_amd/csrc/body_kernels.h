@@ -169,6 +169,7 @@ struct BodyLaunch {
     uint64_t seed = 0, env_offset = 0;
     double dt = 0.002;
     int32_t integrator = 0;
+    int32_t solver = 0;  // enum emei_solver (bodies with several simultaneous constraints)
     NoiseSpec noise;
     EnvParams env_params;
     const void* trig = nullptr;

@@ -1,9 +1,15 @@
 // body_tu.hip — one translation unit per (body, precision), built by the Makefile with
-//   -DEMEI_BODY_FAM_{ch,hp,dp,ip} -DEMEI_BODY_VARIANT=<K> -DEMEI_TU_REAL={double,float} -DEMEI_TU_NAME=<symbol>
+//   -DEMEI_BODY_FAM_{ch,chs,hp,hps,dp,ip} -DEMEI_BODY_VARIANT=<K> -DEMEI_TU_REAL={double,float} -DEMEI_TU_NAME=<symbol>
 #include "body_kernels.h"
 #if defined(EMEI_BODY_FAM_ch)
 #include "cheetah_model.h"
-#define EMEI_BODY_TYPE CheetahBody<EMEI_TU_REAL>
+#define EMEI_BODY_TYPE CheetahBody<EMEI_TU_REAL, EMEI_SOLVER_NEWTON>
+#elif defined(EMEI_BODY_FAM_chs)
+#include "cheetah_model.h"
+#define EMEI_BODY_TYPE CheetahBody<EMEI_TU_REAL, EMEI_SOLVER_SWEEP1>
+#elif defined(EMEI_BODY_FAM_hps)
+#include "hopper_model.h"
+#define EMEI_BODY_TYPE HopperBody<EMEI_TU_REAL, EMEI_SOLVER_SWEEP1>
 #elif defined(EMEI_BODY_FAM_dp)
 #include "dpend_model.h"
 #define EMEI_BODY_TYPE DPendBody<EMEI_BODY_VARIANT, EMEI_TU_REAL>
@@ -12,7 +18,7 @@
 #define EMEI_BODY_TYPE InvPendBody<EMEI_BODY_VARIANT, EMEI_TU_REAL>
 #elif defined(EMEI_BODY_FAM_hp)
 #include "hopper_model.h"
-#define EMEI_BODY_TYPE HopperBody<EMEI_TU_REAL>
+#define EMEI_BODY_TYPE HopperBody<EMEI_TU_REAL, EMEI_SOLVER_NEWTON>
 #else
 #error "body_tu.hip: no EMEI_BODY_FAM_* given"
 #endif

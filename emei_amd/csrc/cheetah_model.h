@@ -18,8 +18,10 @@
 //   * elimination order (leaves first: bfoot, bshin, bthigh, ffoot, fshin, fthigh, torso, x, z)
 //     makes the LDL^T factorisation fill-free; the zero blocks between the two legs are
 //     compile-time zeros of the fully unrolled loops.
-//   * constraints (6 joint limits, 16 capsule-end/floor contact points with friction) follow the
-//     oracle exactly: one Gauss-Seidel sweep in the same fixed order.
+//   * constraints (6 joint limits, 16 capsule-end/floor contact points with friction), two solvers like the oracle
+//     (emei_config.solver): NEWTON (default) = MuJoCo's primal formulation — rows of the pyramidal friction cone,
+//     regularisers from the qpos0 inverse weights, Newton's method to convergence, implicit joint damping after
+//     the solve (accel_newton below) — and SWEEP1 = round 1's single fixed-order Gauss-Seidel sweep (accel).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -202,6 +204,18 @@ constexpr Model cheetah_make_model(double dt) {
 
 // every dt-independent constant of the model, as compile-time immediates for the device code
 __device__ constexpr Model kGeom = cheetah_make_model(0.002);
+
+// Inverse weights at qpos0 (MuJoCo's mj_setConst; the diagonal approximation of J M^-1 J' that scales the constraint
+// regularisers): (M0^-1)_jj of the six leg joints (bthigh .. ffoot) and the mean translational inverse inertia
+// trace(J_com M0^-1 J_com') / 3 of every link in the PERMUTED link order (bfoot, bshin, bthigh, ffoot, fshin, fthigh,
+// torso).  Values generated by oracle/planar_oracle.c:set_invweights (oracle.planar_invweights("cheetah")), which
+// inverts the joint-space inertia at qpos0; tests/test_oracle_cheetah.py pins this table to the oracle's.
+__device__ constexpr double kDofInvWeight0[6] = {2.729788644884895, 5.893248984162908, 8.894877004054672,
+                                                 3.0813926054768794, 6.882795962275771, 9.46813496276976};
+__device__ constexpr double kLinkInvWeight0[7] = {0.2437492834901718, 0.12720922534654563, 0.09691101560963146,
+                                                  0.2661441029233888, 0.1319968179007738, 0.08148379481367078,
+                                                  0.06415751945610275};
+constexpr int kMaxNewton = 24;  // iteration cap of accel_newton (the oracle's statistics: <= 9 over 40 000 random states)
 
 // Sparse LDL^T in the permuted order.  L is stored in the strict lower triangle of A, 1/D in invd.
 template <typename R>
@@ -480,11 +494,297 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     qacc[6] = acc[P_FTHIGH] - acc[P_TORSO], qacc[7] = acc[P_FSHIN] - acc[P_FTHIGH], qacc[8] = acc[P_FFOOT] - acc[P_FSHIN];
 }
 
+// y = A x for the symmetric matrix stored in the lower triangle with the pattern nz()
+template <typename R>
+__device__ __forceinline__ void sym_matvec(const R (&A)[NV][NV], const R (&x)[NV], R (&y)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        R acc = A[i][i] * x[i];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (j < i && nz(i, j)) acc = fma_r(A[i][j], x[j], acc);
+            if (j > i && nz(j, i)) acc = fma_r(A[j][i], x[j], acc);
+        }
+        y[i] = acc;
+    }
+}
+
+// Forward dynamics with MuJoCo's constraint formulation (see oracle/planar_oracle.c, header): the acceleration minimises
+//     1/2 (a - a0)' M (a - a0) + sum_rows D/2 min(0, J a - aref)^2
+// over one row per violated joint limit and the four pyramid edges J_n +- mu J_t, J_n, J_n of every contact point
+// (the two edges along y have no motion to act on in a planar tree).  Newton's method with unit steps on the active
+// set (piecewise-linear gradient with positive definite pieces: converges in <= 9 iterations over the oracle's random
+// states; the oracle itself adds MuJoCo's exact line search — both end at the unique minimiser); H = M + sum D J J' has
+// the fill pattern of M (a contact row lives on a root path), so the sparse LDL^T serves it.  Everything is carried in
+// the absolute-angle coordinates of accel(); `hd` > 0: MuJoCo's Euler applies the joint damping implicitly AFTER the
+// solve, (M + h B) qacc = qfrc_smooth + J' f = M a.
+template <typename R>
+__device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[6], const Model& m, R hd,
+                                             R (&qacc)[NV], const TrigCtx& trig) {
+    R phi[7], om[7];
+    phi[6] = q[2], om[6] = v[2];
+    phi[2] = phi[6] + q[3], om[2] = om[6] + v[3];
+    phi[1] = phi[2] + q[4], om[1] = om[2] + v[4];
+    phi[0] = phi[1] + q[5], om[0] = om[1] + v[5];
+    phi[5] = phi[6] + q[6], om[5] = om[6] + v[6];
+    phi[4] = phi[5] + q[7], om[4] = om[5] + v[7];
+    phi[3] = phi[4] + q[8], om[3] = om[4] + v[8];
+    R cs[7], sn[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) sincos_ctx(trig, phi[b], sn[b], cs[b]);
+    V2<R> S[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
+    const V2<R> Dtb = rot(cs[6], sn[6], (R)kGeom.d_tb[0], (R)kGeom.d_tb[1]);
+    const V2<R> Dtf = rot(cs[6], sn[6], (R)kGeom.d_tf[0], (R)kGeom.d_tf[1]);
+    const V2<R> Dbt = rot(cs[2], sn[2], (R)kGeom.d_bt_bs[0], (R)kGeom.d_bt_bs[1]);
+    const V2<R> Dbs = rot(cs[1], sn[1], (R)kGeom.d_bs_bf[0], (R)kGeom.d_bs_bf[1]);
+    const V2<R> Dft = rot(cs[5], sn[5], (R)kGeom.d_ft_fs[0], (R)kGeom.d_ft_fs[1]);
+    const V2<R> Dfs = rot(cs[4], sn[4], (R)kGeom.d_fs_ff[0], (R)kGeom.d_fs_ff[1]);
+    constexpr int jc[6] = {P_BTHIGH, P_BSHIN, P_BFOOT, P_FTHIGH, P_FSHIN, P_FFOOT};
+    constexpr int jp[6] = {P_TORSO, P_BTHIGH, P_BSHIN, P_TORSO, P_FTHIGH, P_FSHIN};
+
+    // inertia (lower triangle, permuted) with `e_k` added on the joint coordinate theta_k = phi_child - phi_parent
+    auto build_inertia = [&](R (&A)[NV][NV], R hdamp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) A[i][j] = R(0);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) A[b][b] = (R)kGeom.diag[b];
+        A[P_X][P_X] = (R)kGeom.mtot, A[P_Z][P_Z] = (R)kGeom.mtot;
+        A[P_BSHIN][P_BFOOT] = dot(Dbs, S[0]);
+        A[P_BTHIGH][P_BFOOT] = dot(Dbt, S[0]);
+        A[P_BTHIGH][P_BSHIN] = dot(Dbt, S[1]);
+        A[P_TORSO][P_BFOOT] = dot(Dtb, S[0]);
+        A[P_TORSO][P_BSHIN] = dot(Dtb, S[1]);
+        A[P_TORSO][P_BTHIGH] = dot(Dtb, S[2]);
+        A[P_FSHIN][P_FFOOT] = dot(Dfs, S[3]);
+        A[P_FTHIGH][P_FFOOT] = dot(Dft, S[3]);
+        A[P_FTHIGH][P_FSHIN] = dot(Dft, S[4]);
+        A[P_TORSO][P_FFOOT] = dot(Dtf, S[3]);
+        A[P_TORSO][P_FSHIN] = dot(Dtf, S[4]);
+        A[P_TORSO][P_FTHIGH] = dot(Dtf, S[5]);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) A[P_X][b] = S[b].z, A[P_Z][b] = -S[b].x;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const R e = (R)kGeom.arm[k] + hdamp * (R)kGeom.damp[k];
+            A[jc[k]][jc[k]] += e;
+            A[jp[k]][jp[k]] += e;
+            const int hi_ = jc[k] > jp[k] ? jc[k] : jp[k], lo_ = jc[k] > jp[k] ? jp[k] : jc[k];
+            A[hi_][lo_] -= e;
+        }
+    };
+
+    // smooth generalised forces in absolute coordinates (as accel())
+    R f[NV], w2[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) w2[b] = om[b] * om[b];
+    {
+        R fx = R(0), fz = R(0);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) fx = fma_r(w2[b], S[b].x, fx), fz = fma_r(w2[b], S[b].z, fz);
+        f[P_X] = fx;
+        f[P_Z] = fz - (R)kGeom.mtot * (R)kGeom.gravity;
+    }
+    const R g = (R)kGeom.gravity;
+    f[P_BFOOT] = fma_r(g, S[0].x, w2[1] * dotperp(Dbs, S[0]) + w2[2] * dotperp(Dbt, S[0]) + w2[6] * dotperp(Dtb, S[0]));
+    f[P_BSHIN] = fma_r(g, S[1].x, w2[0] * dotperp(S[0], Dbs) + w2[2] * dotperp(Dbt, S[1]) + w2[6] * dotperp(Dtb, S[1]));
+    f[P_BTHIGH] = fma_r(g, S[2].x, w2[0] * dotperp(S[0], Dbt) + w2[1] * dotperp(S[1], Dbt) + w2[6] * dotperp(Dtb, S[2]));
+    f[P_FFOOT] = fma_r(g, S[3].x, w2[4] * dotperp(Dfs, S[3]) + w2[5] * dotperp(Dft, S[3]) + w2[6] * dotperp(Dtf, S[3]));
+    f[P_FSHIN] = fma_r(g, S[4].x, w2[3] * dotperp(S[3], Dfs) + w2[5] * dotperp(Dft, S[4]) + w2[6] * dotperp(Dtf, S[4]));
+    f[P_FTHIGH] = fma_r(g, S[5].x, w2[3] * dotperp(S[3], Dft) + w2[4] * dotperp(S[4], Dft) + w2[6] * dotperp(Dtf, S[5]));
+    f[P_TORSO] = fma_r(g, S[6].x,
+                       w2[0] * dotperp(S[0], Dtb) + w2[1] * dotperp(S[1], Dtb) + w2[2] * dotperp(S[2], Dtb) +
+                           w2[3] * dotperp(S[3], Dtf) + w2[4] * dotperp(S[4], Dtf) + w2[5] * dotperp(S[5], Dtf));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);
+        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.stiff[k] * q[3 + k] - (R)kGeom.damp[k] * v[3 + k];
+        f[jc[k]] += tau;
+        f[jp[k]] -= tau;
+    }
+
+    // ---- which rows exist (geometry only: fixed during the solve): bits 0-5 joint limits, 6-21 contact points
+    const V2<R> o_t = {q[0], (R)kGeom.z0 + q[1]};
+    const V2<R> o_bt = {o_t.x + Dtb.x, o_t.z + Dtb.z}, o_bs = {o_bt.x + Dbt.x, o_bt.z + Dbt.z},
+                o_bf = {o_bs.x + Dbs.x, o_bs.z + Dbs.z};
+    const V2<R> o_ft = {o_t.x + Dtf.x, o_t.z + Dtf.z}, o_fs = {o_ft.x + Dft.x, o_ft.z + Dft.z},
+                o_ff = {o_fs.x + Dfs.x, o_fs.z + Dfs.z};
+    constexpr int pt_link[16] = {P_TORSO, P_TORSO, P_TORSO, P_TORSO, P_BTHIGH, P_BTHIGH, P_BSHIN, P_BSHIN,
+                                 P_BFOOT, P_BFOOT, P_FTHIGH, P_FTHIGH, P_FSHIN, P_FSHIN, P_FFOOT, P_FFOOT};
+    const V2<R> org_of[7] = {o_bf, o_bs, o_bt, o_ff, o_fs, o_ft, o_t};  // by permuted link
+    uint32_t rows = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rows |= ((q[3 + k] < (R)kGeom.lo[k]) | (q[3 + k] > (R)kGeom.hi[k])) ? (1u << k) : 0u;
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) {
+        const int L = pt_link[pt];
+        const R ez = fma_r((R)kGeom.geom_end[pt][1], cs[L], -((R)kGeom.geom_end[pt][0] * sn[L]));
+        rows |= (org_of[L].z + ez - (R)kGeom.radius < R(0)) ? (1u << (6 + pt)) : 0u;
+    }
+
+    // Without rows: qacc = (M + h B)^-1 qfrc_smooth, computed for every lane so that a lane's result never depends on
+    // what the other lanes of its wave do.
+    R A[NV][NV], invd[NV], a[NV];
+    build_inertia(A, hd);
+    ldl_factor(A, invd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = f[i];
+    ldl_forward<0, true>(A, a);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+    ldl_backward(A, a);
+    if (rows != 0u) {  // skipped by a wave in free flight
+        // qacc_smooth: the start of the iteration
+        build_inertia(A, R(0));
+        ldl_factor(A, invd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] = f[i];
+        ldl_forward<0, true>(A, a);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+        ldl_backward(A, a);
+        R u[NV];  // velocities in absolute coordinates
+#pragma unroll
+        for (int b = 0; b < 7; ++b) u[b] = om[b];
+        u[P_X] = v[0], u[P_Z] = v[1];
+        R fmax = R(1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
+
+#pragma unroll 1
+        for (int it = 0; it < kMaxNewton; ++it) {
+            R gr[NV];
+            build_inertia(A, R(0));
+            sym_matvec(A, a, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gr[i] -= f[i];
+            // joint-limit rows
+            auto limit = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
+                if (rows & (1u << k)) {
+                    const R th = q[3 + k];
+                    const bool lower = th < (R)kGeom.lo[k];
+                    const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+                    const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+                    const R x = J * (a[C] - a[P]) - aref;
+                    if (x < R(0)) {
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);  // 1 / R
+                        const R t = Dw * x * J;
+                        gr[C] += t, gr[P] -= t;
+                        A[C][C] += Dw, A[P][P] += Dw;
+                        A[P > C ? P : C][P > C ? C : P] -= Dw;
+                    }
+                }
+            };
+            limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
+            limit(std::integral_constant<int, 3>{}), limit(std::integral_constant<int, 4>{}), limit(std::integral_constant<int, 5>{});
+            // contact rows: the four edges of the pyramid of one capsule end sphere
+            auto contact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
+                               __attribute__((always_inline)) {
+                constexpr int LNK = decltype(lnk_c)::value;
+                if (rows & (1u << (6 + pt))) {
+                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const R dist = org.z + e.z - (R)kGeom.radius;
+                    const V2<R> r = {e.x, R(0.5) * dist - org.z};
+                    R Jx[NV], Jz[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    Jx[LNK] = r.z, Jz[LNK] = -r.x;
+                    if (a1 >= 0) Jx[a1] = v1.z, Jz[a1] = -v1.x;
+                    if (a2 >= 0) Jx[a2] = v2.z, Jz[a2] = -v2.x;
+                    if (a3 >= 0) Jx[a3] = v3.z, Jz[a3] = -v3.x;
+                    R vn = R(0), vt = R(0), an = R(0), at = R(0);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+                        if (in_pat(LNK, i)) {
+                            vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+                            an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
+                        }
+                    const R mu = (R)kGeom.friction;
+                    const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+                    // x_edge = J_edge a - aref_edge, aref_edge = -B (J_edge v) - K imp pos
+                    const R xn = an + (R)m.cB * vn + (R)m.cK * imp * dist, xt = mu * (at + (R)m.cB * vt);
+                    const R x1 = xn + xt, x2 = xn - xt;
+                    const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
+                    if (s1 | s2 | sy) {
+                        // R_edge = 2 mu^2 (1 - imp) / imp * invweight (1 + mu^2)
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * kGeom.friction * kGeom.friction * (1.0 + kGeom.friction * kGeom.friction)) *
+                                                    (R)kLinkInvWeight0[LNK]);
+                        const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
+                        const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
+                        const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);
+#pragma unroll
+                        for (int i = 0; i < NV; ++i)
+                            if (in_pat(LNK, i)) {
+                                gr[i] = fma_r(Jz[i], gn, fma_r(Jx[i], gt, gr[i]));
+                                const R ux = fma_r(wtt, Jx[i], wnt * Jz[i]), uz = fma_r(wnt, Jx[i], wnn * Jz[i]);
+#pragma unroll
+                                for (int j = 0; j <= i; ++j)
+                                    if (in_pat(LNK, j)) A[i][j] = fma_r(ux, Jx[j], fma_r(uz, Jz[j], A[i][j]));
+                            }
+                    }
+                }
+            };
+            const V2<R> none = {R(0), R(0)};
+            using std::integral_constant;
+            contact(0, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+            contact(1, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+            contact(2, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+            contact(3, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+            contact(4, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+            contact(5, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+            contact(6, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+            contact(7, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+            contact(8, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+            contact(9, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+            contact(10, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+            contact(11, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+            contact(12, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+            contact(13, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+            contact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+            contact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+
+            // converged lanes keep stepping (their steps are ~0) until the whole wave is done
+            R gmax = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
+            if (__ballot(!(gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax)) == 0ull) break;
+            ldl_factor(A, invd);
+            ldl_forward<0, true>(A, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gr[i] *= invd[i];
+            ldl_backward(A, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] -= gr[i];
+        }
+        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
+            R rhs[NV];
+            build_inertia(A, R(0));
+            sym_matvec(A, a, rhs);
+            build_inertia(A, hd);
+            ldl_factor(A, invd);
+            ldl_forward<0, true>(A, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = rhs[i] * invd[i];
+            ldl_backward(A, a);
+        }
+    }
+    qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[P_TORSO];
+    qacc[3] = a[P_BTHIGH] - a[P_TORSO], qacc[4] = a[P_BSHIN] - a[P_BTHIGH], qacc[5] = a[P_BFOOT] - a[P_BSHIN];
+    qacc[6] = a[P_FTHIGH] - a[P_TORSO], qacc[7] = a[P_FSHIN] - a[P_FTHIGH], qacc[8] = a[P_FFOOT] - a[P_FSHIN];
+}
+
 }  // namespace cheetah
 
 // ---------------------------------------------------------------------------------------------
 // Body traits for body_kernels.h
-template <typename R>
+// SOLVER: EMEI_SOLVER_NEWTON (MuJoCo's constraint formulation, converged) or EMEI_SOLVER_SWEEP1 (round 1's single sweep)
+template <typename R, int SOLVER = EMEI_SOLVER_NEWTON>
 struct CheetahBody {
     using real = R;
     using Model = cheetah::Model;
@@ -504,7 +804,8 @@ struct CheetahBody {
 
     __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
                                                  const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig) {
-        cheetah::accel(q, v, ctrl, m, hd, qacc, trig);
+        if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) cheetah::accel(q, v, ctrl, m, hd, qacc, trig);
+        else cheetah::accel_newton(q, v, ctrl, m, hd, qacc, trig);
     }
     // obs = concat(qpos, qvel) (mujoco_env.py:153-155); reward half_cheetah.py:59-63 with step() semantics
     // (per env: w_f (x' - x)/dt_env - w_c sum a^2, dt_env = dt*freq_rate); terminal :65-67 (non-finite)

@@ -14,8 +14,9 @@
 //     are Omega_j^2 times the same rotated vectors: 4 sincos per forward-dynamics evaluation.
 //   * the three leg hinges turn about -y (hopper.xml:21,25,29): theta_k = -(phi_child - phi_parent),
 //     so a joint torque tau_k enters as -tau_k on phi_child and +tau_k on phi_parent.
-//   * constraints (3 joint limits, 8 capsule-end/floor contact points with margin and friction)
-//     follow the oracle: one Gauss-Seidel sweep in the same fixed order.
+//   * constraints (3 joint limits, 8 capsule-end/floor contact points with margin and friction): MuJoCo's primal
+//     formulation solved by Newton's method (accel_newton, the default) or round 1's single Gauss-Seidel sweep
+//     (accel), exactly as in cheetah_model.h.
 // The reference steps this env with RK4 by default (hopper.py:22): body_kernels.h:body_substep.
 #pragma once
 #include <cmath>
@@ -101,6 +102,12 @@ constexpr Model make_model(double dt) {
 
 // every dt-independent constant of the model, as compile-time immediates for the device code
 __device__ constexpr Model kGeom = make_model(0.002);
+
+// inverse weights at qpos0 (see cheetah_model.h:kDofInvWeight0): joints thigh, leg, foot; links in chain order foot, leg,
+// thigh, torso.  Generated by oracle/planar_oracle.c:set_invweights (oracle.planar_invweights("hopper")).
+__device__ constexpr double kDofInvWeight0[3] = {0.9173573040079778, 0.8423092317158415, 0.9000381439194954};
+__device__ constexpr double kLinkInvWeight0[NL] = {0.0669027107682187, 0.04959511864425974, 0.05192331014610705,
+                                                   0.08492239638897525};
 
 // dense LDL^T of the symmetric 6x6 (lower triangle of A); L in the strict lower triangle, 1/D in invd
 template <typename R>
@@ -298,10 +305,226 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     qacc[3] = acc[L_TORSO] - acc[L_THIGH], qacc[4] = acc[L_THIGH] - acc[L_LEG], qacc[5] = acc[L_LEG] - acc[L_FOOT];
 }
 
+// y = A x, A symmetric in its lower triangle
+template <typename R>
+__device__ __forceinline__ void sym_matvec(const R (&A)[NV][NV], const R (&x)[NV], R (&y)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        R acc = A[i][i] * x[i];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (j < i) acc = fma_r(A[i][j], x[j], acc);
+            if (j > i) acc = fma_r(A[j][i], x[j], acc);
+        }
+        y[i] = acc;
+    }
+}
+
+// Forward dynamics with MuJoCo's constraint formulation: see cheetah_model.h:accel_newton (same scheme, single chain).
+template <typename R>
+__device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
+                                             R (&qacc)[NV], const TrigCtx& trig) {
+    R phi[NL], om[NL];
+    phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
+    phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
+    phi[L_LEG] = phi[L_THIGH] - q[4], om[L_LEG] = om[L_THIGH] - v[4];
+    phi[L_FOOT] = phi[L_LEG] - q[5], om[L_FOOT] = om[L_LEG] - v[5];
+    R cs[NL], sn[NL], w2[NL];
+    V2<R> S[NL], D[NL];
+#pragma unroll
+    for (int b = 0; b < NL; ++b) {
+        sincos_ctx(trig, phi[b], sn[b], cs[b]);
+        S[b] = rot(cs[b], sn[b], (R)kGeom.sx[b], (R)kGeom.sz[b]);
+        D[b] = rot(cs[b], sn[b], (R)kGeom.d[b][0], (R)kGeom.d[b][1]);
+        w2[b] = om[b] * om[b];
+    }
+    constexpr int jc[3] = {L_THIGH, L_LEG, L_FOOT}, jp[3] = {L_TORSO, L_THIGH, L_LEG};
+    auto build_inertia = [&](R (&A)[NV][NV], R hdamp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) A[i][j] = R(0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            A[i][i] = (R)kGeom.diag[i];
+            A[P_X][i] = S[i].z, A[P_Z][i] = -S[i].x;
+#pragma unroll
+            for (int j = 0; j < i; ++j) A[i][j] = dot(D[i], S[j]);
+        }
+        A[P_X][P_X] = (R)kGeom.mtot, A[P_Z][P_Z] = (R)kGeom.mtot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const R e = (R)kGeom.arm[k] + hdamp * (R)kGeom.damp[k];
+            A[jc[k]][jc[k]] += e, A[jp[k]][jp[k]] += e, A[jp[k]][jc[k]] -= e;
+        }
+    };
+    R f[NV];
+    const R g = (R)kGeom.gravity;
+    {
+        R fx = R(0), fz = R(0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            R fi = g * S[i].x;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                if (j < i) fi = fma_r(w2[j], dotperp(S[j], D[i]), fi);
+                else if (j > i) fi = fma_r(w2[j], dotperp(D[j], S[i]), fi);
+            }
+            f[i] = fi;
+            fx = fma_r(w2[i], S[i].x, fx), fz = fma_r(w2[i], S[i].z, fz);
+        }
+        f[P_X] = fx, f[P_Z] = fz - (R)kGeom.mtot * g;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);
+        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
+        f[jc[k]] -= tau;
+        f[jp[k]] += tau;
+    }
+    V2<R> org[NL];
+    org[L_TORSO] = V2<R>{q[0], (R)kGeom.z0 + q[1]};
+    org[L_THIGH] = V2<R>{org[L_TORSO].x + D[L_TORSO].x, org[L_TORSO].z + D[L_TORSO].z};
+    org[L_LEG] = V2<R>{org[L_THIGH].x + D[L_THIGH].x, org[L_THIGH].z + D[L_THIGH].z};
+    org[L_FOOT] = V2<R>{org[L_LEG].x + D[L_LEG].x, org[L_LEG].z + D[L_LEG].z};
+    // rows that exist (geometry only): bits 0-2 joint limits, 3-10 contact points
+    uint32_t rows = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rows |= ((q[3 + k] < (R)kGeom.lo[k]) | (q[3 + k] > (R)kGeom.hi[k])) ? (1u << k) : 0u;
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const int gi = pt / 2, L = L_TORSO - gi;
+        const R ez = fma_r((R)kGeom.geom_end[pt][1], cs[L], -((R)kGeom.geom_end[pt][0] * sn[L]));
+        rows |= (org[L].z + ez - (R)kGeom.radius[gi] < (R)kGeom.margin) ? (1u << (3 + pt)) : 0u;
+    }
+    // without rows: qacc = (M + h B)^-1 qfrc_smooth, for every lane (results independent of the rest of the wave)
+    R A[NV][NV], invd[NV], a[NV];
+    build_inertia(A, hd);
+    ldl_factor(A, invd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = f[i];
+    ldl_forward<0>(A, a);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+    ldl_backward(A, a);
+    if (rows != 0u) {
+        build_inertia(A, R(0));
+        ldl_factor(A, invd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] = f[i];
+        ldl_forward<0>(A, a);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+        ldl_backward(A, a);
+        R u[NV];
+#pragma unroll
+        for (int b = 0; b < NL; ++b) u[b] = om[b];
+        u[P_X] = v[0], u[P_Z] = v[1];
+        R fmax = R(1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
+#pragma unroll 1
+        for (int it = 0; it < cheetah::kMaxNewton; ++it) {
+            R gr[NV];
+            build_inertia(A, R(0));
+            sym_matvec(A, a, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gr[i] -= f[i];
+            auto limit = [&](auto kc) __attribute__((always_inline)) {  // theta_k = phi_P - phi_C: J = +-(e_P - e_C)
+                constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
+                if (rows & (1u << k)) {
+                    const R th = q[3 + k];
+                    const bool lower = th < (R)kGeom.lo[k];
+                    const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+                    const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+                    const R x = J * (a[P] - a[C]) - aref;
+                    if (x < R(0)) {
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);
+                        const R t = Dw * x * J;
+                        gr[P] += t, gr[C] -= t;
+                        A[C][C] += Dw, A[P][P] += Dw, A[P][C] -= Dw;  // P > C
+                    }
+                }
+            };
+            limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
+            auto contact = [&](auto pt_c) __attribute__((always_inline)) {
+                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+                if (rows & (1u << (3 + pt))) {
+                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
+                    const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
+                    R Jx[NV], Jz[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    Jx[LNK] = r.z, Jz[LNK] = -r.x;
+#pragma unroll
+                    for (int b = LNK + 1; b < NL; ++b) Jx[b] = D[b].z, Jz[b] = -D[b].x;
+                    R vn = R(0), vt = R(0), an = R(0), at = R(0);
+#pragma unroll
+                    for (int i = LNK; i < NV; ++i) {
+                        vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+                        an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
+                    }
+                    constexpr double mu_c = kGeom.friction[gi];
+                    const R mu = (R)mu_c;
+                    const R pos = dist - (R)kGeom.margin;
+                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+                    const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
+                    const R x1 = xn + xt, x2 = xn - xt;
+                    const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
+                    if (s1 | s2 | sy) {
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c)) * (R)kLinkInvWeight0[LNK]);
+                        const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
+                        const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
+                        const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);
+#pragma unroll
+                        for (int i = LNK; i < NV; ++i) {
+                            gr[i] = fma_r(Jz[i], gn, fma_r(Jx[i], gt, gr[i]));
+                            const R ux = fma_r(wtt, Jx[i], wnt * Jz[i]), uz = fma_r(wnt, Jx[i], wnn * Jz[i]);
+#pragma unroll
+                            for (int j = LNK; j <= i; ++j) A[i][j] = fma_r(ux, Jx[j], fma_r(uz, Jz[j], A[i][j]));
+                        }
+                    }
+                }
+            };
+            using std::integral_constant;
+            contact(integral_constant<int, 0>{}), contact(integral_constant<int, 1>{}), contact(integral_constant<int, 2>{});
+            contact(integral_constant<int, 3>{}), contact(integral_constant<int, 4>{}), contact(integral_constant<int, 5>{});
+            contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
+            R gmax = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
+            if (__ballot(!(gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax)) == 0ull) break;
+            ldl_factor(A, invd);
+            ldl_forward<0>(A, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gr[i] *= invd[i];
+            ldl_backward(A, gr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] -= gr[i];
+        }
+        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
+            R rhs[NV];
+            build_inertia(A, R(0));
+            sym_matvec(A, a, rhs);
+            build_inertia(A, hd);
+            ldl_factor(A, invd);
+            ldl_forward<0>(A, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = rhs[i] * invd[i];
+            ldl_backward(A, a);
+        }
+    }
+    qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[L_TORSO];
+    qacc[3] = a[L_TORSO] - a[L_THIGH], qacc[4] = a[L_THIGH] - a[L_LEG], qacc[5] = a[L_LEG] - a[L_FOOT];
+}
+
 }  // namespace hopper
 
 // Body traits for body_kernels.h
-template <typename R>
+template <typename R, int SOLVER = EMEI_SOLVER_NEWTON>
 struct HopperBody {
     using real = R;
     using Model = hopper::Model;
@@ -322,7 +545,8 @@ struct HopperBody {
 
     __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
                                                  R (&qacc)[6], const TrigCtx& trig) {
-        hopper::accel(q, v, ctrl, m, hd, qacc, trig);
+        if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) hopper::accel(q, v, ctrl, m, hd, qacc, trig);
+        else hopper::accel_newton(q, v, ctrl, m, hd, qacc, trig);
     }
     // hopper.py:79-93 as executed: np.logical_and(healthy_state, healthy_z, healthy_angle) takes the
     // third argument as `out=`, so the angle range is never applied

@@ -65,10 +65,12 @@ class Engine:
 
     def __init__(self, env_name, n_envs, freq_rate=1, real_time_scale=0.02, precision="ref", max_episode_steps=0,
                  device=None, seed=0, env_index_offset=0, init_noise=0.0, integrator="euler", obs_noise=0.0,
-                 noise_layout="iid", env_params=None):
+                 noise_layout="iid", env_params=None, solver="newton"):
         """init_noise / obs_noise: one sigma, a (qpos sigma, qvel sigma) pair, or one sigma per state coordinate
         (qpos entries then qvel entries): the reduced forms of mujoco_env.py:218-227.
-        env_params: {name: value} overriding reward / health constructor defaults (names: _lib.ENV_PARAMS)."""
+        env_params: {name: value} overriding reward / health constructor defaults (names: _lib.ENV_PARAMS).
+        solver: constraint solver of HalfCheetah / Hopper: "newton" (MuJoCo's formulation, converged; the default) or
+        "sweep1" (round 1's single Gauss-Seidel sweep)."""
         if env_name not in L.ENV_IDS:
             raise ValueError(f"unknown env {env_name!r}; known: {sorted(L.ENV_IDS)}")
         if integrator not in L.INTEGRATORS:
@@ -81,13 +83,16 @@ class Engine:
         self.precision = {"ref": L.PRECISION_REF, "f32": L.PRECISION_F32}[precision]
         self.obs_dim, self.act_dim, self.state_dim = env_dims(env_name)
         self.integrator = integrator
+        if solver not in L.SOLVERS:
+            raise ValueError(f"solver {solver!r}; known: {sorted(L.SOLVERS)}")
+        self.solver = solver
         sig = C.c_float * L.MAX_STATE_DIM
         cfg = L.EmeiConfig(C.sizeof(L.EmeiConfig), L.ENV_IDS[env_name], self.n_envs, self.freq_rate, self.precision,
                            self.real_time_scale, int(max_episode_steps), self.device.index, int(seed),
                            int(env_index_offset), 0.0, L.INTEGRATORS[integrator],
                            {"iid": L.NOISE_IID, "shared": L.NOISE_SHARED}[noise_layout],
                            sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)),
-                           *((lambda m, a: (m, 0, a))(*L.pack_env_params(env_params))))
+                           *((lambda m, a: (m, L.SOLVERS[solver], a))(*L.pack_env_params(env_params))))
         self._h = C.c_void_p()
         self._host_io = None
         with torch.cuda.device(self.device):

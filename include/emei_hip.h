@@ -67,6 +67,13 @@ enum emei_integrator { EMEI_INTEG_EULER = 0, EMEI_INTEG_SEMI_IMPLICIT = 1, EMEI_
  *            slicing of mujoco_env.py:243-244 adds ONE draw to every qpos entry and ONE to every qvel */
 enum emei_noise_layout { EMEI_NOISE_IID = 0, EMEI_NOISE_SHARED = 1 };
 
+/* Constraint solver of the MuJoCo-backed bodies with several simultaneous constraints (HalfCheetah, Hopper):
+ * NEWTON : MuJoCo's primal formulation as documented — one row per violated joint limit, the 2 (condim - 1) edges of the
+ *          pyramidal friction cone per contact, regularisers from the qpos0 inverse weights — solved to convergence
+ *          by Newton's method on the active set; Euler's implicit joint damping applied after the solve (the default)
+ * SWEEP1 : one fixed-order Gauss-Seidel sweep with box-clamped friction (round 1; ~5x cheaper, kept for comparison) */
+enum emei_solver { EMEI_SOLVER_NEWTON = 0, EMEI_SOLVER_SWEEP1 = 1 };
+
 /* dtype of the `actions` argument of emei_step / emei_rollout. */
 enum emei_action_dtype { EMEI_ACT_U8 = 0, EMEI_ACT_I32 = 1, EMEI_ACT_I64 = 2, EMEI_ACT_F32 = 3 };
 
@@ -131,7 +138,7 @@ typedef struct emei_config {
     /* -- from struct_size 400: constructor parameters of the reward / terminal functions.  Bit k of
      *    env_param_mask set = env_params[k] overrides the reference's default (enum emei_env_param). ---- */
     uint32_t env_param_mask;
-    uint32_t reserved0;
+    uint32_t solver;            /* enum emei_solver (this field was `reserved0`, always 0, before) */
     double env_params[EMEI_MAX_ENV_PARAMS];
 } emei_config;
 #define EMEI_CONFIG_SIZE_V1 64u

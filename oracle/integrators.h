@@ -29,7 +29,10 @@ typedef struct {
     float obs_pos, obs_vel;
     uint64_t seed, env_offset;
     uint32_t episode, step_index; /* counter words of the noise stream (same for every env of the call) */
+    int32_t solver;               /* constraint solver of the planar bodies: ORACLE_SOLVER_* (0 = MuJoCo's: converged Newton) */
+    int32_t reserved;
 } oracle_opts_t;
+enum { ORACLE_SOLVER_NEWTON = 0, ORACLE_SOLVER_SWEEP1 = 1 };
 
 /* forward dynamics: qacc at (q, v); hd = dt when joint damping is integrated implicitly, else 0 */
 typedef void (*oracle_accel_fn)(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl,

@@ -159,15 +159,19 @@ class Opts(C.Structure):
     """oracle_opts_t (integrators.h)."""
 
     _fields_ = [("integrator", C.c_int32), ("shared", C.c_int32), ("obs_pos", C.c_float), ("obs_vel", C.c_float),
-                ("seed", C.c_uint64), ("env_offset", C.c_uint64), ("episode", C.c_uint32), ("step_index", C.c_uint32)]
+                ("seed", C.c_uint64), ("env_offset", C.c_uint64), ("episode", C.c_uint32), ("step_index", C.c_uint32),
+                ("solver", C.c_int32), ("reserved", C.c_int32)]
 
 
-def opts(integrator="euler", obs_noise=0.0, shared=False, seed=0, env_offset=0, episode=0, step_index=0):
+SOLVERS = {"newton": 0, "sweep1": 1}
+
+
+def opts(integrator="euler", obs_noise=0.0, shared=False, seed=0, env_offset=0, episode=0, step_index=0, solver="newton"):
     """Options of the *_step functions: integrator (mujoco_env.py:70-79) and per-substep observation noise
     (:98-104) drawn from the device's counter-based stream at (seed, env, episode, step_index)."""
     p, v = (obs_noise if isinstance(obs_noise, (tuple, list)) else (obs_noise, obs_noise))
     return Opts(INTEGRATORS[integrator], int(bool(shared)), float(p), float(v), int(seed), int(env_offset), int(episode),
-                int(step_index))
+                int(step_index), SOLVERS[solver], 0)
 
 
 def _o(o):
@@ -310,6 +314,27 @@ def planar_inertia(body, q, v):
     lib().planar_oracle_inertia(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(v, C.c_double),
                                 _p(M, C.c_double), _p(b, C.c_double), C.byref(e))
     return M, b, e.value
+
+
+def planar_solve(body, q, v, ctrl, dt=0.002, hd=0.0):
+    """One forward-dynamics evaluation of the planar-tree oracle with the Newton solver (MuJoCo's formulation) and
+    with the one-sweep solver -> dict(acc_newton, acc_sweep1, nrows, iters, resid)."""
+    nv = 9 if body == "cheetah" else 6
+    q, v, ctrl = (np.ascontiguousarray(x, np.float64) for x in (q, v, ctrl))
+    an, a1 = np.empty(nv), np.empty(nv)
+    nr, it, res = C.c_int(), C.c_int(), C.c_double()
+    lib().planar_oracle_solve(C.c_int(0 if body == "cheetah" else 1), C.c_double(dt), C.c_double(hd), _p(q, C.c_double),
+                              _p(v, C.c_double), _p(ctrl, C.c_double), _p(an, C.c_double), _p(a1, C.c_double), C.byref(nr),
+                              C.byref(it), C.byref(res))
+    return dict(acc_newton=an, acc_sweep1=a1, nrows=nr.value, iters=it.value, resid=res.value)
+
+
+def planar_invweights(body):
+    """(dof_invweight0 [nv], body_invweight0 [nb]) of the planar-tree oracle at qpos0 (mj_setConst)."""
+    nv, nb = (9, 7) if body == "cheetah" else (6, 4)
+    d, b = np.empty(nv), np.empty(nb)
+    lib().planar_oracle_invweights(C.c_int(0 if body == "cheetah" else 1), _p(d, C.c_double), _p(b, C.c_double))
+    return d, b
 
 
 def planar_geometry(body, q):

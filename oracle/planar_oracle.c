@@ -13,11 +13,20 @@
  * recursive Newton-Euler for the bias forces, unit-acceleration RNE columns for the joint-space
  * inertia, spring/damper passive forces, armature, Euler with implicit joint damping or RK4, soft
  * constraints with solref/solimp impedance — combined with emei's integrator switch
- * (mujoco_env.py:70-79,94-97,189-191; integrators.h).  One documented simplification: the
- * constraint forces (joint limits, capsule/floor contacts with friction) are obtained by ONE
- * fixed-order Gauss-Seidel sweep over the active constraints (limits first, then contact points in
- * geom order; normal then tangent inside a contact) with regulariser R = (1-d)/d * A_ii, instead of
- * MuJoCo's converged Newton solve with pyramidal cones.  The HIP kernels implement the same models
+ * (mujoco_env.py:70-79,94-97,189-191; integrators.h).  Constraint forces (joint limits, capsule/floor
+ * contacts with friction), two selectable solvers (oracle_opts_t.solver):
+ *   NEWTON (default) MuJoCo's own formulation as its documentation states it ("Computation" chapter): the
+ *          acceleration minimises  1/2 (a - a0)' M (a - a0) + sum_i s_i(J_i a - aref_i),  s_i(x) = D_i x^2 / 2 for
+ *          x < 0, over the active rows — one row per violated joint limit, the 2 (condim - 1) = 4 edges
+ *          J_n +- mu J_t of the PYRAMIDAL friction cone (MuJoCo's default cone) per contact — with
+ *          R_i = 1 / D_i = (1 - d) / d * diagApprox_i from the qpos0 inverse weights (dof_invweight0 for a limit;
+ *          body_invweight0 (1 + mu^2), times 2 mu^2, for a pyramid edge), solved to convergence by Newton's method
+ *          with an exact line search (mj_solNewton's scheme; MuJoCo itself stops at tolerance 1e-8), and the Euler
+ *          integrator's implicit joint damping applied AFTER the solve, (M + h B) qacc = qfrc_smooth + J' f.
+ *   SWEEP1 round 1's simplification, kept for the speed comparison: ONE fixed-order Gauss-Seidel sweep (limits first,
+ *          then contact points in geom order; normal then box-clamped tangent inside a contact) with regulariser
+ *          R = (1-d)/d * A_ii and the implicit damping folded into the matrix the sweep uses.
+ * The HIP kernels implement the same models
  * with a different formulation (absolute-angle closed forms, emei_amd/csrc/cheetah_model.h and
  * hopper_model.h), so kernel-vs-oracle agreement checks both.
  *
@@ -70,8 +79,13 @@ typedef struct {
     /* solref / solimp: contacts and joint limits */
     double c_tc, c_dr, c_dmin, c_dmax, c_width;
     double l_tc, l_dr, l_dmin, l_dmax, l_width;
+    /* inverse weights at qpos0 (mj_setConst): (M0^-1)_jj per dof; mean translational inverse inertia per body,
+     * trace(J_com M0^-1 J_com') / 3 over the three world axes (a planar tree never moves along y) */
+    double dof_invweight0[NV], body_invweight0[NB];
+    int solver; /* ORACLE_SOLVER_* */
 } planar_model_t;
 typedef planar_model_t cheetah_model_t;
+static void set_invweights(planar_model_t* m);
 
 static double capsule_mass(double rho, double r, double half) {
     return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r);
@@ -148,6 +162,7 @@ EXPORT void cheetah_oracle_model(planar_model_t* m) {
     m->gravity = 9.81;
     m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.0, m->c_dmax = 0.8, m->c_width = 0.01;
     m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.0, m->l_dmax = 0.8, m->l_width = 0.03;
+    set_invweights(m);
 }
 EXPORT int cheetah_oracle_model_size(void) { return (int)sizeof(planar_model_t); }
 
@@ -188,6 +203,7 @@ EXPORT void hopper_oracle_model(planar_model_t* m) {
     m->gravity = 9.81;
     m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.8, m->c_dmax = 0.8, m->c_width = 0.01;
     m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.9, m->l_dmax = 0.95, m->l_width = 0.001; /* MuJoCo joint defaults */
+    set_invweights(m);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -284,9 +300,222 @@ static double impedance(double dist, double dmin, double dmax, double width) {
     return d < 1e-4 ? 1e-4 : (d > 0.9999 ? 0.9999 : d); /* mjMINIMP, mjMAXIMP */
 }
 
-/* forward dynamics (mj_forward): qacc at (q, v).  hd = dt for MuJoCo's Euler (implicit joint damping:
- * (M + h D) qacc = f), 0 for RK4. */
+/* joint-space inertia (armature included) and smooth forces at (q, v) */
+static void smooth_terms(const planar_model_t* m, const kin_t* k, const double* q, const double* v, const double* ctrl,
+                         double M[NV][NV], double* f) {
+    const int nv = m->nv;
+    double zero[NV] = {0}, bias[NV];
+    rnea(m, k, v, zero, m->gravity, bias);
+    for (int c = 0; c < nv; ++c) { /* inertia column c = RNE with unit acceleration, no velocity, no gravity */
+        double e[NV] = {0}, col[NV];
+        e[c] = 1;
+        rnea(m, k, zero, e, 0.0, col);
+        for (int r = 0; r < nv; ++r) M[r][c] = col[r];
+    }
+    for (int i = 0; i < nv; ++i) {
+        f[i] = -bias[i] - m->stiffness[i] * q[i] - m->damping[i] * v[i]; /* passive: spring to 0, damper */
+        M[i][i] += m->armature[i];
+    }
+    for (int a = 0; a < m->nu; ++a) {
+        double c = ctrl[a] < -1 ? -1 : (ctrl[a] > 1 ? 1 : ctrl[a]); /* ctrllimited, ctrlrange +-1 */
+        f[m->act_dof[a]] += m->gear[a] * c;
+    }
+}
+
+/* mj_setConst: inverse weights at qpos0 */
+static void set_invweights(planar_model_t* m) {
+    const int nv = m->nv;
+    double q0[NV] = {0}, M[NV][NV], f[NV], ctrl0[NU] = {0};
+    q0[1] = m->z_ref; /* qpos0 of a joint with `ref` is its ref */
+    kin_t k;
+    kinematics(m, q0, &k);
+    smooth_terms(m, &k, q0, q0 + 0 * nv, ctrl0, M, f); /* v = 0: only M is used */
+    ldl_factor(nv, M);
+    for (int j = 0; j < nv; ++j) {
+        double e[NV] = {0};
+        e[j] = 1;
+        ldl_solve(nv, M, e);
+        m->dof_invweight0[j] = e[j];
+    }
+    for (int b = 0; b < m->nb; ++b) {
+        double Jx[NV], Jz[NV], wx[NV], wz[NV], A = 0;
+        point_jacobian(m, &k, b, k.com[b], Jx, Jz);
+        memcpy(wx, Jx, sizeof(wx)), memcpy(wz, Jz, sizeof(wz));
+        ldl_solve(nv, M, wx), ldl_solve(nv, M, wz);
+        for (int r = 0; r < nv; ++r) A += Jx[r] * wx[r] + Jz[r] * wz[r];
+        m->body_invweight0[b] = A / 3.0;
+    }
+}
+
+/* one scalar constraint row of the primal problem: cost D/2 (J.a - aref)^2 where negative */
+typedef struct { double J[NV], aref, D; } crow_t;
+#define MAXROWS (NV + 4 * 2 * NG)
+#define MJ_MINVAL 1e-15
+
+static int build_rows(const planar_model_t* m, const kin_t* k, double dt, const double* q, const double* v, crow_t* rows) {
+    const int nv = m->nv;
+    int nr = 0;
+    double l_tc = m->l_tc < 2 * dt ? 2 * dt : m->l_tc, c_tc = m->c_tc < 2 * dt ? 2 * dt : m->c_tc; /* refsafe */
+    for (int i = 3; i < nv; ++i) { /* joint limits (mjCNSTR_LIMIT_JOINT), margin 0 */
+        double dist, J;
+        if (!m->limited[i]) continue;
+        if (q[i] - m->range_lo[i] < 0) dist = q[i] - m->range_lo[i], J = 1;
+        else if (m->range_hi[i] - q[i] < 0) dist = m->range_hi[i] - q[i], J = -1;
+        else continue;
+        crow_t* r = &rows[nr++];
+        memset(r, 0, sizeof(*r));
+        r->J[i] = J;
+        double imp = impedance(dist, m->l_dmin, m->l_dmax, m->l_width);
+        double K = 1 / (m->l_dmax * m->l_dmax * l_tc * l_tc * m->l_dr * m->l_dr), B = 2 / (m->l_dmax * l_tc);
+        r->aref = -B * (J * v[i]) - K * imp * dist;
+        double R = (1 - imp) / imp * m->dof_invweight0[i];
+        r->D = 1.0 / (R > MJ_MINVAL ? R : MJ_MINVAL);
+    }
+    double cK = 1 / (m->c_dmax * m->c_dmax * c_tc * c_tc * m->c_dr * m->c_dr), cB = 2 / (m->c_dmax * c_tc);
+    for (int g = 0; g < m->ng; ++g) { /* capsule end spheres against the floor plane z = 0 (mjCNSTR_CONTACT_PYRAMIDAL) */
+        int b = m->geom_body[g];
+        for (int e = 0; e < 2; ++e) {
+            v2 s = add(k->org[b], rot(k->phi[b], m->geom_end[g][e]));
+            double dist = s.z - m->geom_radius[g];
+            if (!(dist < m->contact_margin)) continue;
+            v2 p = V(s.x, 0.5 * dist); /* MuJoCo places the contact midway between the surfaces */
+            double Jx[NV], Jz[NV];
+            point_jacobian(m, k, b, p, Jx, Jz);
+            double pos = dist - m->contact_margin, mu = m->geom_friction[g];
+            double imp = impedance(pos, m->c_dmin, m->c_dmax, m->c_width);
+            double R = (1 - imp) / imp * (m->body_invweight0[b] * (1 + mu * mu)); /* diagApprox of a pyramid edge */
+            double Rpy = 2 * mu * mu * R;
+            double D = 1.0 / (Rpy > MJ_MINVAL ? Rpy : MJ_MINVAL);
+            /* edges n + mu t, n - mu t in the plane; the two edges n +- mu y of condim 3 have no y-motion to act on: J_n */
+            const double sgn[4] = {1, -1, 0, 0};
+            for (int ed = 0; ed < 4; ++ed) {
+                crow_t* r = &rows[nr++];
+                double Jv = 0;
+                for (int c = 0; c < NV; ++c) r->J[c] = c < nv ? Jz[c] + sgn[ed] * mu * Jx[c] : 0.0;
+                for (int c = 0; c < nv; ++c) Jv += r->J[c] * v[c];
+                r->aref = -cB * Jv - cK * imp * pos;
+                r->D = D;
+            }
+        }
+    }
+    return nr;
+}
+
+static void matvec(int n, const double A[NV][NV], const double* x, double* y) {
+    for (int r = 0; r < n; ++r) {
+        y[r] = 0;
+        for (int c = 0; c < n; ++c) y[r] += A[r][c] * x[c];
+    }
+}
+
+/* MuJoCo's constraint solve restated: Newton on the primal cost with an exact line search, to convergence.
+ * *iters_out / *resid_out (optional): iterations used and the final scaled gradient norm. */
+static void newton_solve(int nv, const double M[NV][NV], const double* a0, int nr, const crow_t* rows, double* a, int* iters_out,
+                         double* resid_out) {
+    double scale = 0; /* 1 / (mean inertia * nv), mj_solNewton's scaling of the gradient */
+    for (int i = 0; i < nv; ++i) scale += M[i][i];
+    scale = 1.0 / scale;
+    memcpy(a, a0, nv * sizeof(double));
+    int it = 0;
+    double gn = 0;
+    for (; it < 200; ++it) {
+        double H[NV][NV], g[NV], d[NV], da[NV], Mda[NV];
+        for (int i = 0; i < nv; ++i) da[i] = a[i] - a0[i];
+        matvec(nv, M, da, g);
+        memcpy(H, M, sizeof(H));
+        for (int r = 0; r < nr; ++r) {
+            double x = -rows[r].aref;
+            for (int c = 0; c < nv; ++c) x += rows[r].J[c] * a[c];
+            if (!(x < 0)) continue;
+            for (int i = 0; i < nv; ++i) {
+                g[i] += rows[r].D * x * rows[r].J[i];
+                for (int j = 0; j < nv; ++j) H[i][j] += rows[r].D * rows[r].J[i] * rows[r].J[j];
+            }
+        }
+        gn = 0;
+        for (int i = 0; i < nv; ++i) gn += g[i] * g[i];
+        gn = sqrt(gn) * scale;
+        if (gn < 1e-11) break; /* MuJoCo's own tolerance is 1e-8; the rounding floor of this gradient is ~1e-13 */
+        ldl_factor(nv, H);
+        for (int i = 0; i < nv; ++i) d[i] = -g[i];
+        ldl_solve(nv, H, d);
+        /* exact line search: phi'(alpha) = d.M (a + alpha d - a0) + sum_active D (x_r + alpha jd_r) jd_r is piecewise linear
+         * and increasing; Newton on it from alpha = 1 (the minimiser when the active set does not change), bisection guard */
+        matvec(nv, M, d, Mda);
+        double dMd = 0, dMa = 0;
+        for (int i = 0; i < nv; ++i) dMd += d[i] * Mda[i], dMa += Mda[i] * da[i];
+        double xr[MAXROWS], jd[MAXROWS];
+        for (int r = 0; r < nr; ++r) {
+            xr[r] = -rows[r].aref, jd[r] = 0;
+            for (int c = 0; c < nv; ++c) xr[r] += rows[r].J[c] * a[c], jd[r] += rows[r].J[c] * d[c];
+        }
+        double lo = 0, hi = -1, alpha = 1;
+        for (int ls = 0; ls < 100; ++ls) {
+            double p1 = dMa + alpha * dMd, p2 = dMd;
+            for (int r = 0; r < nr; ++r) {
+                double x = xr[r] + alpha * jd[r];
+                if (x < 0) p1 += rows[r].D * x * jd[r], p2 += rows[r].D * jd[r] * jd[r];
+            }
+            if (fabs(p1) <= 1e-15 * (fabs(dMa) + fabs(dMd) + 1e-300)) break;
+            if (p1 > 0) hi = alpha; else lo = alpha;
+            double next = alpha - p1 / p2;
+            if (hi > 0 && !(next > lo && next < hi)) next = 0.5 * (lo + hi);
+            if (hi < 0 && !(next > lo)) next = 2 * alpha;
+            if (fabs(next - alpha) <= 1e-16 * fabs(alpha)) { alpha = next; break; }
+            alpha = next;
+        }
+        for (int i = 0; i < nv; ++i) a[i] += alpha * d[i];
+    }
+    if (iters_out) *iters_out = it;
+    if (resid_out) *resid_out = gn;
+}
+
+/* forward dynamics with MuJoCo's constraint formulation (see the header): qacc at (q, v); hd = dt for the Euler
+ * integrator (implicit joint damping after the solve), 0 for RK4 */
+static void planar_accel_newton(const planar_model_t* m, double dt, double hd, const double* q, const double* v, const double* ctrl,
+                                double* acc, int* iters_out, double* resid_out, int* nrows_out) {
+    const int nv = m->nv;
+    kin_t k;
+    kinematics(m, q, &k);
+    double M[NV][NV], L[NV][NV], f[NV], a0[NV], a[NV];
+    smooth_terms(m, &k, q, v, ctrl, M, f);
+    memcpy(L, M, sizeof(L));
+    ldl_factor(nv, L);
+    memcpy(a0, f, nv * sizeof(double));
+    ldl_solve(nv, L, a0); /* qacc_smooth */
+    crow_t rows[MAXROWS];
+    int nr = build_rows(m, &k, dt, q, v, rows);
+    if (nrows_out) *nrows_out = nr;
+    if (nr == 0) {
+        memcpy(a, a0, nv * sizeof(double));
+        if (iters_out) *iters_out = 0;
+        if (resid_out) *resid_out = 0;
+    } else {
+        newton_solve(nv, M, a0, nr, rows, a, iters_out, resid_out);
+    }
+    if (hd > 0) { /* mj_EulerSkip: (M + h B) qacc = qfrc_smooth + qfrc_constraint = M a at the optimum */
+        double rhs[NV];
+        matvec(nv, M, a, rhs);
+        for (int i = 0; i < nv; ++i) M[i][i] += hd * m->damping[i];
+        ldl_factor(nv, M);
+        ldl_solve(nv, M, rhs);
+        memcpy(acc, rhs, nv * sizeof(double));
+    } else {
+        memcpy(acc, a, nv * sizeof(double));
+    }
+}
+
+static void planar_accel_sweep1(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc);
+/* forward dynamics (mj_forward): qacc at (q, v) with the solver the model selects */
 static void planar_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc) {
+    const planar_model_t* m = (const planar_model_t*)ctx;
+    if (m->solver == ORACLE_SOLVER_SWEEP1) planar_accel_sweep1(ctx, dt, hd, q, v, ctrl, acc);
+    else planar_accel_newton(m, dt, hd, q, v, ctrl, acc, NULL, NULL, NULL);
+}
+
+/* SWEEP1 (round 1).  hd = dt for MuJoCo's Euler (implicit joint damping folded into the matrix:
+ * (M + h D) qacc = f), 0 for RK4. */
+static void planar_accel_sweep1(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc) {
     const planar_model_t* m = (const planar_model_t*)ctx;
     const int nv = m->nv;
     kin_t k;
@@ -388,6 +617,7 @@ EXPORT void cheetah_oracle_step_p(int64_t n, int freq_rate, double dt, double* s
     const double* P = params ? params : kCheetahDefaults;
     planar_model_t m;
     cheetah_oracle_model(&m);
+    m.solver = opts ? opts->solver : ORACLE_SOLVER_NEWTON;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double* s = state + 18 * i;
@@ -443,6 +673,7 @@ EXPORT void hopper_oracle_step_p(int64_t n, int freq_rate, double dt, double* st
     const double* P = params ? params : kHopperDefaults;
     planar_model_t m;
     hopper_oracle_model(&m);
+    m.solver = opts ? opts->solver : ORACLE_SOLVER_NEWTON;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double* s = state + 12 * i;
@@ -474,6 +705,24 @@ EXPORT void hopper_oracle_is_healthy_p(int64_t n, const double* obs, const doubl
 }
 EXPORT void hopper_oracle_is_healthy(int64_t n, const double* obs, uint8_t* out) {
     hopper_oracle_is_healthy_p(n, obs, NULL, out, NULL);
+}
+
+/* diagnostics for the tests: one forward-dynamics evaluation with the Newton solver and what it took — active rows,
+ * iterations, final scaled gradient norm — plus, for comparison, the one-sweep acceleration (either output may be NULL) */
+EXPORT void planar_oracle_solve(int body, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc_newton,
+                                double* acc_sweep1, int* nrows, int* iters, double* resid) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    double a[NV];
+    planar_accel_newton(&m, dt, hd, q, v, ctrl, a, iters, resid, nrows);
+    if (acc_newton) memcpy(acc_newton, a, m.nv * sizeof(double));
+    if (acc_sweep1) planar_accel_sweep1(&m, dt, hd, q, v, ctrl, acc_sweep1);
+}
+EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    memcpy(dof_out, m.dof_invweight0, m.nv * sizeof(double));
+    memcpy(body_out, m.body_invweight0, m.nb * sizeof(double));
 }
 
 /* diagnostics for the tests: mass matrix [nv,nv], bias and total mechanical energy at (q, v); body 0 = cheetah, 1 = hopper */

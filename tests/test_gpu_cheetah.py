@@ -28,17 +28,20 @@ def _states(rng, n):
 
 @pytest.mark.parametrize("fr,dt", [(1, 0.002), (4, 0.002), (2, 0.01)])
 @pytest.mark.parametrize("precision", ["ref", "f32"])
-def test_onestep_vs_oracle(fr, dt, precision):
+@pytest.mark.parametrize("solver", ["newton", "sweep1"])
+def test_onestep_vs_oracle(fr, dt, precision, solver):
+    """both constraint solvers: MuJoCo's formulation solved to convergence (kernel: unit-step Newton on the active set;
+    oracle: Newton with exact line search — the same unique minimiser) and round 1's single Gauss-Seidel sweep"""
     from oracle import oracle as O
 
     rng = np.random.default_rng(3)
     n = 1000  # ragged last wave
     s0 = _states(rng, n)
     act = rng.uniform(-1.3, 1.3, (n, 6)).astype(np.float32)
-    eng = _engine("HalfCheetahRunning", n, freq_rate=fr, real_time_scale=dt, precision=precision)
+    eng = _engine("HalfCheetahRunning", n, freq_rate=fr, real_time_scale=dt, precision=precision, solver=solver)
     eng.set_state(s0)
     obs, rew, done = eng.step(torch.as_tensor(act, device=eng.device))
-    o_st, o_rew, o_term = O.cheetah_step(s0, act.astype(np.float64), fr, dt)
+    o_st, o_rew, o_term = O.cheetah_step(s0, act.astype(np.float64), fr, dt, O.opts(solver=solver))
     if precision == "ref":
         assert rel_err(eng.get_state().cpu().numpy(), o_st, floor=1.0) <= 1e-9
         assert rel_err(obs.cpu().numpy(), o_st) <= 1e-5

@@ -33,17 +33,18 @@ def _states(rng, n):
 
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 @pytest.mark.parametrize("fr,dt", [(1, 0.002), (4, 0.002), (2, 0.01)])
-def test_onestep_vs_oracle(integrator, fr, dt):
+@pytest.mark.parametrize("solver", ["newton", "sweep1"])
+def test_onestep_vs_oracle(integrator, fr, dt, solver):
     from oracle import oracle as O
 
     rng = np.random.default_rng(3)
     n = 1000  # ragged last wave
     s0 = _states(rng, n)
     act = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32)
-    eng = _engine("HopperRunning", n, freq_rate=fr, real_time_scale=dt, integrator=integrator)
+    eng = _engine("HopperRunning", n, freq_rate=fr, real_time_scale=dt, integrator=integrator, solver=solver)
     eng.set_state(s0)
     obs, rew, done = eng.step(torch.as_tensor(act, device=eng.device))
-    o_st, o_rew, o_term = O.hopper_step(s0, act.astype(np.float64), fr, dt, O.opts(integrator))
+    o_st, o_rew, o_term = O.hopper_step(s0, act.astype(np.float64), fr, dt, O.opts(integrator, solver=solver))
     assert rel_err(eng.get_state().cpu().numpy(), o_st, floor=1.0) <= 1e-9
     assert rel_err(obs.cpu().numpy(), o_st) <= 1e-5
     assert rel_err(rew.cpu().numpy(), o_rew) <= 1e-5
