@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
     ap.add_argument("--integrator", default=None, choices=["euler", "semi_implicit_euler", "rk4"],
                     help="MuJoCo-backed bodies only (mujoco_env.py:70-79); default: the workload's own")
+    ap.add_argument("--solver", default="newton", choices=["newton", "sweep1"],
+                    help="constraint solver of the HalfCheetah / Hopper workloads: MuJoCo's formulation solved to convergence "
+                         "(default) or round 1's single Gauss-Seidel sweep")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed clock-settle phase before the warm-up passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
@@ -145,7 +148,7 @@ def main():
     chunk = a.chunk if T % a.chunk == 0 else T
     sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
                         rank=rank, world=world, device=local_rank, seed=0,
-                        integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk)
+                        integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk, solver=a.solver)
     desc = w["desc"]
     if sharded_cartpole and a.workload == "cartpole_swingup" and N == MULTI_GPU_SHARD:
         desc = (f"CartPoleSwingUp-v0, {world * N} parallel envs sharded {world}xMI355X ({N} per GPU) with RCCL all-gather of obs"
@@ -208,7 +211,7 @@ def main():
     traffic = valu = None
     prof = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and N == w["n"] and T_launch == w["horizon"] and a.precision == "ref" and not a.integrator:
+    if os.path.exists(tpath) and N == w["n"] and T_launch == w["horizon"] and a.precision == "ref" and not a.integrator and a.solver == "newton":
         try:
             prof = json.load(open(tpath)).get(a.workload, {})
             traffic, valu = prof.get("bytes_per_launch"), prof.get("valu_insts_per_launch")
@@ -220,7 +223,8 @@ def main():
         "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if a.precision == "ref" else "f32", "data": "synthetic",
         "config": {"workload": desc, "env": env, "envs_per_gpu": N, "horizon": T, "freq_rate": w["freq_rate"],
-                   "real_time_scale": w["dt"], "settle_ms_before_warmup": a.settle_ms, "integrator": a.integrator or w.get("integrator", "euler"), "api": f"emei_rollout ({'one launch per horizon' if sr.n_chunks == 1 else f'{sr.n_chunks} launches of {sr.chunk} steps per horizon'}, device auto-reset)",
+                   "real_time_scale": w["dt"], "settle_ms_before_warmup": a.settle_ms, "integrator": a.integrator or w.get("integrator", "euler"),
+                   "constraint_solver": a.solver if a.workload in ("cheetah", "hopper") else "n/a (at most one constraint row)", "api": f"emei_rollout ({'one launch per horizon' if sr.n_chunks == 1 else f'{sr.n_chunks} launches of {sr.chunk} steps per horizon'}, device auto-reset)",
                    "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
                    "gather": gather, "chunk_steps": sr.chunk,
                    "obs_allgather": ({"final": "last [n,obs_dim] observation of each pass",

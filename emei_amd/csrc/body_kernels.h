@@ -5,7 +5,9 @@
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
 //   struct Model; make_model(dt, env_params)        // run-time constants, passed by value as a kernel argument
-//   accel(q, v, ctrl, m, hd, qacc, trig)            // forward dynamics incl. soft constraints; `hd` = dt when
+//   struct Warm; accel(q, v, ctrl, m, hd, qacc, trig, warm)   // forward dynamics incl. soft constraints; `warm` carries the
+//                                                   // constraint solver's start from one evaluation to the next
+//                                                   // WITHIN an env-step (reset at every step); `hd` = dt when
 //                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0;
 //                                                   // `trig` = the {sin,cos} table staged in LDS (emei_device.h)
 //   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal, trig)   // obs / reward / terminal of a finished step
@@ -99,7 +101,8 @@ __device__ __forceinline__ void body_init(typename Body::real (&s)[Body::NS], ui
 // F = (v, qacc(q, v)) with the full forward dynamics (constraints included) at every stage.
 template <class Body, bool RK4>
 __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS], const typename Body::real (&ctrl)[Body::NA],
-                                             const typename Body::Model& m, bool semi, const TrigCtx& trig) {
+                                             const typename Body::Model& m, bool semi, const TrigCtx& trig,
+                                             typename Body::Warm& warm) {
     using R = typename Body::real;
     constexpr int NV = Body::NS / 2;
     const R dt = (R)m.dt;
@@ -107,7 +110,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
 #pragma unroll
     for (int i = 0; i < NV; ++i) q[i] = s[i], v[i] = s[NV + i];
     if constexpr (!RK4) {
-        Body::accel(q, v, ctrl, m, dt, acc, trig);
+        Body::accel(q, v, ctrl, m, dt, acc, trig, warm);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const R vn = fma_r(dt, acc[i], v[i]);
@@ -124,7 +127,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
         // form (caught by tests/test_gpu_integrators.py).  The Hopper must NOT: unrolled under its 256-register cap it
         // spills six times the algorithmic bytes to scratch.
         auto stage = [&](int st) __attribute__((always_inline)) {
-            Body::accel(qs, vs, ctrl, m, R(0), acc, trig);
+            Body::accel(qs, vs, ctrl, m, R(0), acc, trig, warm);
             const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);
             const R h = dt * (st == 2 ? R(1) : R(0.5));  // step to the NEXT stage state
 #pragma unroll
@@ -285,8 +288,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
         R pre[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) pre[k] = s[k];
+        typename Body::Warm warm{};  // per env-step: a fused rollout and repeated emei_step calls iterate identically
         for (int k = 0; k < a.freq_rate; ++k) {  // mujoco_env.py:91-104
-            body_substep<Body, RK4>(s, ctrl, a.m, a.semi != 0, trig);
+            body_substep<Body, RK4>(s, ctrl, a.m, a.semi != 0, trig, warm);
             if (obs_noise)
                 gauss_state<R, NS, false>(s, a.seed ^ kObsNoiseKey, a.env_offset + (uint64_t)i, episode,
                                           ((uint32_t)steps * (uint32_t)a.freq_rate + (uint32_t)k) * (uint32_t)((NS + 3) / 4),
@@ -440,7 +444,8 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < NS; ++k) s[k] = pre[k] = (R)obs[i * NO + k];
 #pragma unroll
     for (int k = 0; k < NA; ++k) ctrl[k] = (R)actions[i * NA + k];
-    for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0, trig);
+    typename Body::Warm warm{};
+    for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0, trig, warm);
     float o[NO];
     bool term;
     Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term, trig);

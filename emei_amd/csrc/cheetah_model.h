@@ -215,7 +215,10 @@ __device__ constexpr double kDofInvWeight0[6] = {2.729788644884895, 5.8932489841
 __device__ constexpr double kLinkInvWeight0[7] = {0.2437492834901718, 0.12720922534654563, 0.09691101560963146,
                                                   0.2661441029233888, 0.1319968179007738, 0.08148379481367078,
                                                   0.06415751945610275};
-constexpr int kMaxNewton = 24;  // iteration cap of accel_newton (the oracle's statistics: <= 9 over 40 000 random states)
+#ifndef EMEI_MAX_NEWTON
+#define EMEI_MAX_NEWTON 24
+#endif
+constexpr int kMaxNewton = EMEI_MAX_NEWTON;  // iteration cap of accel_newton (the oracle's statistics: <= 9 over 40 000 random states)
 
 // Sparse LDL^T in the permuted order.  L is stored in the strict lower triangle of A, 1/D in invd.
 template <typename R>
@@ -518,9 +521,16 @@ __device__ __forceinline__ void sym_matvec(const R (&A)[NV][NV], const R (&x)[NV
 // the fill pattern of M (a contact row lives on a root path), so the sparse LDL^T serves it.  Everything is carried in
 // the absolute-angle coordinates of accel(); `hd` > 0: MuJoCo's Euler applies the joint damping implicitly AFTER the
 // solve, (M + h B) qacc = qfrc_smooth + J' f = M a.
+// `warm`: the minimiser of the previous evaluation of the same env-step (substeps, RK4 stages): consecutive states share
+// their active set almost always, and Newton started there needs one step instead of ~5.
+template <typename R>
+struct NewtonWarm {
+    R a[NV];
+    bool valid;
+};
 template <typename R>
 __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[6], const Model& m, R hd,
-                                             R (&qacc)[NV], const TrigCtx& trig) {
+                                             R (&qacc)[NV], const TrigCtx& trig, NewtonWarm<R>& warm) {
     R phi[7], om[7];
     phi[6] = q[2], om[6] = v[2];
     phi[2] = phi[6] + q[3], om[2] = om[6] + v[3];
@@ -646,6 +656,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] *= invd[i];
         ldl_backward(A, a);
+        if (warm.valid) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
+        }
         R u[NV];  // velocities in absolute coordinates
 #pragma unroll
         for (int b = 0; b < 7; ++b) u[b] = om[b];
@@ -687,7 +701,13 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                                __attribute__((always_inline)) {
                 constexpr int LNK = decltype(lnk_c)::value;
                 if (rows & (1u << (6 + pt))) {
-                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    // The geometry of a point does not change during the iteration, so hipcc would hoist all of it (16
+                    // points x ~15 doubles) out of the Newton loop and spill ~1 KB per lane to scratch around every
+                    // evaluation — measured: 3x the time of the whole solve.  An opaque copy of the link's sin / cos
+                    // makes the block recompute instead (~40 instructions per active point and pass).
+                    R csl = cs[LNK], snl = sn[LNK];
+                    asm volatile("" : "+v"(csl), "+v"(snl));
+                    const V2<R> e = rot(csl, snl, (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
                     const R dist = org.z + e.z - (R)kGeom.radius;
                     const V2<R> r = {e.x, R(0.5) * dist - org.z};
                     R Jx[NV], Jz[NV];
@@ -729,6 +749,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                             }
                     }
                 }
+                // one row block at a time: without the fence hipcc interleaves the 16 blocks (and their geometry) for ILP
+                // and the live ranges spill ~1 KB per lane to scratch
+                __builtin_amdgcn_sched_barrier(0);
             };
             const V2<R> none = {R(0), R(0)};
             using std::integral_constant;
@@ -762,6 +785,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
+        warm.valid = true;
         if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
             R rhs[NV];
             build_inertia(A, R(0));
@@ -802,10 +828,12 @@ struct CheetahBody {
         return m;
     }
 
+    struct WarmNone {};
+    using Warm = std::conditional_t<SOLVER == EMEI_SOLVER_SWEEP1, WarmNone, cheetah::NewtonWarm<R>>;
     __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
-                                                 const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig) {
+                                                 const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig, Warm& warm) {
         if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) cheetah::accel(q, v, ctrl, m, hd, qacc, trig);
-        else cheetah::accel_newton(q, v, ctrl, m, hd, qacc, trig);
+        else cheetah::accel_newton(q, v, ctrl, m, hd, qacc, trig, warm);
     }
     // obs = concat(qpos, qvel) (mujoco_env.py:153-155); reward half_cheetah.py:59-63 with step() semantics
     // (per env: w_f (x' - x)/dt_env - w_c sum a^2, dt_env = dt*freq_rate); terminal :65-67 (non-finite)

@@ -73,8 +73,9 @@ struct DPendBody {
     static Model make_model(double dt, const EnvParams&) { return dpend::make_model(VARIANT >= 2, dt); }
 
     // q = (x, theta1, theta2), v = (v, omega1, omega2); no joint damping in this model, so `hd` is unused
+    struct Warm {};  // a single constraint row: solved exactly in one step
     __device__ __forceinline__ static void accel(const R (&q)[3], const R (&v)[3], const R (&ctrl)[NA], const Model& m, R,
-                                                 R (&qacc)[3], const TrigCtx& trig) {
+                                                 R (&qacc)[3], const TrigCtx& trig, Warm&) {
         const R phi1 = q[1] + (R)m.phi_off, phi2 = phi1 + q[2];
         const R w1 = v[1], w2 = v[1] + v[2];
         R s1, c1, s2, c2;

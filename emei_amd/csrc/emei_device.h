@@ -31,11 +31,21 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ void sincos_fast_r(double x, double& s, double& c) { fast_sincos(x, s, c); }
 __device__ __forceinline__ void sincos_fast_r(float x, float& s, float& c) { fast_sincosf(x, s, c); }
 // repair of a fast result for out-of-range arguments; call it at the END of a straight-line block
+// The cold path is entered through a WAVE-UNIFORM test (a scalar branch on the ballot), and masks its lanes inside.  The
+// plain `if (cold)` form compiles to `s_and_saveexec; s_cbranch_execnz COLD; JOIN: ...; s_or_b64 exec`, and hipcc may
+// put register spill stores at the top of JOIN, in front of the EXEC restore, where they execute with EXEC = 0 in every
+// normal step (the cheetah RK4 miscompile; tests/test_isa_guards.py audits the shipped kernels for it).
 __device__ __forceinline__ void sincos_repair_r(double x, double& s, double& c) {
-    if (__builtin_expect(fabs(x) > kFastTrigLimitF64, 0)) ::sincos(x, &s, &c);
+    const bool cold = fabs(x) > kFastTrigLimitF64;
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {
+        if (cold) ::sincos(x, &s, &c);
+    }
 }
 __device__ __forceinline__ void sincos_repair_r(float x, float& s, float& c) {
-    if (__builtin_expect(fabsf(x) > kFastTrigLimitF32, 0)) ::sincosf(x, &s, &c);
+    const bool cold = fabsf(x) > kFastTrigLimitF32;
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {
+        if (cold) ::sincosf(x, &s, &c);
+    }
 }
 template <typename T>
 __device__ __forceinline__ void sincos_r(T x, T& s, T& c) {
@@ -82,8 +92,12 @@ __device__ __forceinline__ double trig_reduce_large(double x) {
 }
 // the argument the table path sees: x itself in every practical case
 __device__ __forceinline__ double trig_arg(double x) {
-    if (__builtin_expect(!(__builtin_fabs(x) <= kFastTrigLimitF64), 0)) return trig_reduce_large(x);
-    return x;
+    const bool cold = !(__builtin_fabs(x) <= kFastTrigLimitF64);
+    double r = x;
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {  // wave-uniform entry: see sincos_repair_r
+        if (cold) r = trig_reduce_large(x);
+    }
+    return r;
 }
 
 // Trig context of the cart/pole kernels: float64 uses the 256-entry {sin,cos} table every kernel

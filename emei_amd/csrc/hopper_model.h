@@ -322,8 +322,13 @@ __device__ __forceinline__ void sym_matvec(const R (&A)[NV][NV], const R (&x)[NV
 
 // Forward dynamics with MuJoCo's constraint formulation: see cheetah_model.h:accel_newton (same scheme, single chain).
 template <typename R>
+struct NewtonWarm {
+    R a[NV];
+    bool valid;
+};
+template <typename R>
 __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
-                                             R (&qacc)[NV], const TrigCtx& trig) {
+                                             R (&qacc)[NV], const TrigCtx& trig, NewtonWarm<R>& warm) {
     R phi[NL], om[NL];
     phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
     phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
@@ -416,6 +421,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] *= invd[i];
         ldl_backward(A, a);
+        if (warm.valid) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
+        }
         R u[NV];
 #pragma unroll
         for (int b = 0; b < NL; ++b) u[b] = om[b];
@@ -451,7 +460,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             auto contact = [&](auto pt_c) __attribute__((always_inline)) {
                 constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
                 if (rows & (1u << (3 + pt))) {
-                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    R csl = cs[LNK], snl = sn[LNK];  // opaque: keeps the point's geometry inside the loop (cheetah_model.h)
+                    asm volatile("" : "+v"(csl), "+v"(snl));
+                    const V2<R> e = rot(csl, snl, (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
                     R Jx[NV], Jz[NV];
@@ -505,6 +516,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
+        warm.valid = true;
         if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
             R rhs[NV];
             build_inertia(A, R(0));
@@ -528,7 +542,8 @@ template <typename R, int SOLVER = EMEI_SOLVER_NEWTON>
 struct HopperBody {
     using real = R;
     using Model = hopper::Model;
-    static constexpr int kMinWavesPerEU = 2;
+    // single sweep: the 256-register cap buys a second resident wave; the Newton solve needs the whole file
+    static constexpr int kMinWavesPerEU = SOLVER == EMEI_SOLVER_SWEEP1 ? 2 : 1;
     static constexpr bool kUnrollRK4 = false;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
@@ -543,10 +558,12 @@ struct HopperBody {
         return m;
     }
 
+    struct WarmNone {};
+    using Warm = std::conditional_t<SOLVER == EMEI_SOLVER_SWEEP1, WarmNone, hopper::NewtonWarm<R>>;
     __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
-                                                 R (&qacc)[6], const TrigCtx& trig) {
+                                                 R (&qacc)[6], const TrigCtx& trig, Warm& warm) {
         if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) hopper::accel(q, v, ctrl, m, hd, qacc, trig);
-        else hopper::accel_newton(q, v, ctrl, m, hd, qacc, trig);
+        else hopper::accel_newton(q, v, ctrl, m, hd, qacc, trig, warm);
     }
     // hopper.py:79-93 as executed: np.logical_and(healthy_state, healthy_z, healthy_angle) takes the
     // third argument as `out=`, so the angle range is never applied

@@ -69,8 +69,9 @@ struct InvPendBody {
     static Model make_model(double dt, const EnvParams&) { return ipend::make_model(VARIANT >= 2, dt); }
 
     // q = (x, theta), v = (xdot, omega); no joint damping in this model (`hd` unused)
+    struct Warm {};  // a single constraint row: solved exactly in one step
     __device__ __forceinline__ static void accel(const R (&q)[2], const R (&v)[2], const R (&ctrl)[NA], const Model& m, R,
-                                                 R (&qacc)[2], const TrigCtx& trig) {
+                                                 R (&qacc)[2], const TrigCtx& trig, Warm&) {
         R sn, cs;
         sincos_ctx(trig, q[1] + (R)m.phi_off, sn, cs);
         const R M11 = (R)m.M11, M22 = (R)m.M22, M12 = (R)m.mpr * cs;

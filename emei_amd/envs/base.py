@@ -22,7 +22,7 @@ class HipEnv(EmeiEnv):
                  num_envs: int = 1, precision: str = "ref", device: Optional[int] = None,
                  max_episode_steps: Optional[int] = None, auto_reset: bool = False, init_noise=0.0,
                  env_index_offset: int = 0, obs_noise=0.0, noise_layout: Optional[str] = None,
-                 render_mode: Optional[str] = None, engine_env_params: Optional[dict] = None):
+                 render_mode: Optional[str] = None, engine_env_params: Optional[dict] = None, solver: str = "newton"):
         if render_mode is not None:
             # base_control.py:15,21 / mujoco_env.py:33 accept "human" / "rgb_array"; pygame and the MuJoCo viewer
             # are outside the env-step path
@@ -39,6 +39,7 @@ class HipEnv(EmeiEnv):
         self._init_noise = init_noise
         self._engine_env_params = dict(engine_env_params or {})  # non-default reward / health parameters (_lib.ENV_PARAMS)
         self._obs_noise = obs_noise
+        self._solver = solver  # constraint solver of the multi-constraint bodies (HalfCheetah, Hopper): "newton" | "sweep1"
         # the reference only works for B = 1, where its row slicing shares one draw over all of qpos and
         # one over all of qvel (mujoco_env.py:243-244); the vectorised form draws per coordinate
         self._noise_layout = noise_layout or ("shared" if self.num_envs == 1 else "iid")
@@ -85,7 +86,7 @@ class HipEnv(EmeiEnv):
                                   max_episode_steps=self.max_episode_steps, device=self.device_index,
                                   env_index_offset=self._env_index_offset, init_noise=self._init_noise,
                                   integrator=self.ENGINE_INTEGRATOR or "euler", obs_noise=self._obs_noise,
-                                  noise_layout=self._noise_layout, env_params=self._engine_env_params)
+                                  noise_layout=self._noise_layout, env_params=self._engine_env_params, solver=self._solver)
         return self._engine
 
     def _host_init_state(self, batch_size) -> np.ndarray:
@@ -253,10 +254,16 @@ def joint_sigmas(params, nq):
     return np.full(nq, float(params)), np.full(nq, float(params))
 
 
+class ParityUnpinnedWarning(UserWarning):
+    """The dynamics of a MuJoCo-backed env are a restatement of MuJoCo's published algorithms, not libmujoco itself."""
+
+
 class MujocoHipEnv(HipEnv):
     """The part of EmeiMujocoEnv (mujoco_env.py:23-62,130-155,197-249) that is first-party Python:
     constructor kwargs, init state + Gaussian init noise, obs = concat(qpos, qvel).  The MuJoCo
     arithmetic itself is the engine's closed-form body model (parity unpinned)."""
+
+    _warned = set()
 
     NQ = None  # number of (slide/hinge) joints = len(qpos) = len(qvel)
     INIT_QPOS = None  # non-zero entries of init_qpos (the Hopper's rootz ref); None = zeros
@@ -266,6 +273,16 @@ class MujocoHipEnv(HipEnv):
         if integrator not in ("euler", "semi_implicit_euler", "rk4"):
             raise NotImplementedError(f"integrator {integrator!r}")  # mujoco_env.py:78-79
         self.ENGINE_INTEGRATOR = integrator
+        if type(self).__name__ not in MujocoHipEnv._warned:  # once per env class
+            import warnings
+
+            MujocoHipEnv._warned.add(type(self).__name__)
+            warnings.warn(
+                f"{type(self).__name__}: the reference steps this env with the third-party `mujoco` package (mujoco_env.py:93), "
+                "which is not available to this build.  The engine restates MuJoCo's published pipeline (inertia from geoms, "
+                "soft constraints with solref / solimp, pyramidal friction cones, converged Newton solve, implicit joint damping); "
+                "rewards, terminals, observation layout, integrator switch and noise routines are pinned to the reference, the "
+                "next-state values are NOT pinned against libmujoco (DESIGN.md, section 5).", ParityUnpinnedWarning, stacklevel=3)
         self.init_noise_params, self.obs_noise_params = init_noise_params, obs_noise_params
         super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator,
                          init_noise=np.concatenate(joint_sigmas(init_noise_params, self.NQ)).tolist(),

@@ -173,3 +173,21 @@ def test_offline_dataset_lookup_is_local_only(tmp_path, monkeypatch):
     datasets.save_for_env(env, bad, "broken")
     with pytest.raises(AssertionError, match="Dataset is missing key timeouts"):  # core.py:118-126
         env.get_dataset("broken")
+
+
+def test_mujoco_backed_envs_warn_that_parity_is_unpinned():
+    """the MuJoCo-backed env classes present themselves as drop-in equivalents, so constructing one says — once
+    per class — that its next-state values are not pinned against libmujoco."""
+    import warnings
+
+    import emei_amd
+    from emei_amd.envs.base import MujocoHipEnv, ParityUnpinnedWarning
+
+    MujocoHipEnv._warned.discard("HopperRunningEnv")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        emei_amd.HopperRunningEnv()
+        emei_amd.HopperRunningEnv()
+        emei_amd.CartPoleSwingUpEnv()  # first-party dynamics, pinned: no warning
+    got = [x for x in w if issubclass(x.category, ParityUnpinnedWarning)]
+    assert len(got) == 1 and "libmujoco" in str(got[0].message)
