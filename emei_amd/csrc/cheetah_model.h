@@ -27,6 +27,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "constexpr_math.h"
 #include "emei_device.h"
 
 namespace emei {
@@ -88,32 +89,9 @@ namespace cheetah_host {
 struct H2 {
     double x, z;
 };
-// sin / cos for compile-time evaluation (|a| of a few radians; Taylor after reduction to [-pi/4, pi/4], ~1e-16)
-constexpr void ce_sincos(double a, double& sn, double& cs) {
-    const double pio2_hi = 1.5707963267948966, pio2_lo = 6.123233995736766e-17;
-    const double kq = a / pio2_hi;
-    const long k = (long)(kq + (kq >= 0 ? 0.5 : -0.5));
-    const double r = (a - k * pio2_hi) - k * pio2_lo, z = r * r;
-    double ts = 0, tc = 0;
-    for (int n = 10; n >= 0; --n) {  // sum_{n} (-1)^n z^n / (2n+1)!  and  / (2n)!
-        double fs = 1, fc = 1;
-        for (int q = 1; q <= 2 * n + 1; ++q) fs *= q;
-        for (int q = 1; q <= 2 * n; ++q) fc *= q;
-        ts = ts * z + ((n & 1) ? -1.0 : 1.0) / fs;
-        tc = tc * z + ((n & 1) ? -1.0 : 1.0) / fc;
-    }
-    // Horner above folds z^n in ascending order of n from the highest term down: ts = sum c_n z^n
-    const double s0 = r * ts, c0 = tc;
-    switch (((k % 4) + 4) % 4) {
-        case 0: sn = s0, cs = c0; break;
-        case 1: sn = c0, cs = -s0; break;
-        case 2: sn = -s0, cs = -c0; break;
-        default: sn = -c0, cs = s0; break;
-    }
-}
-constexpr H2 hrot(double a, H2 v) {
+constexpr H2 hrot(double a, H2 v) {  // compile-time rotation (constexpr_math.h)
     double sn = 0, cs = 0;
-    ce_sincos(a, sn, cs);
+    ce::sincos(a, sn, cs);
     return {v.x * cs + v.z * sn, -v.x * sn + v.z * cs};
 }
 constexpr double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
