@@ -72,8 +72,8 @@ template <typename R>
 __device__ __forceinline__ R dotperp(V2<R> a, V2<R> b) { return fma_r(a.x, b.z, -(a.z * b.x)); }
 
 template <typename R>
-__device__ __forceinline__ R impedance(R dist, R dmin, R dmax, R width) {
-    R x = div_r(fabs(dist), width);
+__device__ __forceinline__ R impedance(R dist, R dmin, R dmax, R inv_width) {  // inv_width: a compile-time 1 / solimp width
+    R x = fabs(dist) * inv_width;
     R y = x >= R(1) ? R(1) : (x <= R(0.5) ? R(2) * x * x : R(1) - R(2) * (R(1) - x) * (R(1) - x));
     R d = dmin + y * (dmax - dmin);
     return d < R(1e-4) ? R(1e-4) : (d > R(0.9999) ? R(0.9999) : d);
@@ -371,7 +371,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
             for (int i = 0; i < NV; ++i)
                 if (in_pat(C, i)) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
-            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = div_r(R(1) - imp, imp) * Aii;
             const R force = div_r(aref - acur, Aii + Rr);
@@ -431,7 +431,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                     Ann = fma_r(Jz[i], dz[i], Ann), Att = fma_r(Jx[i], dx[i], Att), Atn = fma_r(Jx[i], dz[i], Atn);
                     an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
                 }
-            const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+            const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
             const R k1 = div_r(R(1) - imp, imp);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * dist - an, Ann + k1 * Ann);
             if (fn > R(0)) {
@@ -509,6 +509,7 @@ struct NewtonWarm {
 template <typename R>
 __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[6], const Model& m, R hd,
                                              R (&qacc)[NV], const TrigCtx& trig, NewtonWarm<R>& warm) {
+    EMEI_MARK(nw_trig);
     R phi[7], om[7];
     phi[6] = q[2], om[6] = v[2];
     phi[2] = phi[6] + q[3], om[2] = om[6] + v[3];
@@ -565,6 +566,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         }
     };
 
+    EMEI_MARK(nw_forces);
     // smooth generalised forces in absolute coordinates (as accel())
     R f[NV], w2[7];
 #pragma unroll
@@ -594,6 +596,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         f[jp[k]] -= tau;
     }
 
+    EMEI_MARK(nw_rows);
     // ---- which rows exist (geometry only: fixed during the solve): bits 0-5 joint limits, 6-21 contact points
     const V2<R> o_t = {q[0], (R)kGeom.z0 + q[1]};
     const V2<R> o_bt = {o_t.x + Dtb.x, o_t.z + Dtb.z}, o_bs = {o_bt.x + Dbt.x, o_bt.z + Dbt.z},
@@ -613,20 +616,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         rows |= (org_of[L].z + ez - (R)kGeom.radius < R(0)) ? (1u << (6 + pt)) : 0u;
     }
 
-    // Without rows: qacc = (M + h B)^-1 qfrc_smooth, computed for every lane so that a lane's result never depends on
-    // what the other lanes of its wave do.
+    EMEI_MARK(nw_direct);
+    EMEI_STAT_LANE(0);
+    EMEI_STAT_WAVE(7);
     R A[NV][NV], invd[NV], a[NV];
-    build_inertia(A, hd);
-    ldl_factor(A, invd);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = f[i];
-    ldl_forward<0, true>(A, a);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-    ldl_backward(A, a);
-    if (rows != 0u) {  // skipped by a wave in free flight
-        // qacc_smooth: the start of the iteration
-        build_inertia(A, R(0));
+    if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
+        build_inertia(A, hd);
         ldl_factor(A, invd);
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] = f[i];
@@ -634,9 +629,22 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] *= invd[i];
         ldl_backward(A, a);
+    } else {
+    EMEI_MARK(nw_smooth0);
+        EMEI_STAT_LANE(1);
+        // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
         if (warm.valid) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
+        } else {
+            build_inertia(A, R(0));
+            ldl_factor(A, invd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = f[i];
+            ldl_forward<0, true>(A, a);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+            ldl_backward(A, a);
         }
         R u[NV];  // velocities in absolute coordinates
 #pragma unroll
@@ -646,21 +654,28 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
 
+        [[maybe_unused]] int n_pass = 0;
 #pragma unroll 1
         for (int it = 0; it < kMaxNewton; ++it) {
+    EMEI_MARK(nw_pass_base);
             R gr[NV];
+            ++n_pass;
+            EMEI_STAT_LANE(2);
+            EMEI_STAT_WAVE(3);
             build_inertia(A, R(0));
             sym_matvec(A, a, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gr[i] -= f[i];
+    EMEI_MARK(nw_limits);
             // joint-limit rows
             auto limit = [&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
+                    EMEI_STAT_WAVE(6);
                     const R th = q[3 + k];
                     const bool lower = th < (R)kGeom.lo[k];
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
-                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
                     const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
                     const R x = J * (a[C] - a[P]) - aref;
                     if (x < R(0)) {
@@ -674,11 +689,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             };
             limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
             limit(std::integral_constant<int, 3>{}), limit(std::integral_constant<int, 4>{}), limit(std::integral_constant<int, 5>{});
+    EMEI_MARK(nw_contacts);
             // contact rows: the four edges of the pyramid of one capsule end sphere
             auto contact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
                                __attribute__((always_inline)) {
                 constexpr int LNK = decltype(lnk_c)::value;
                 if (rows & (1u << (6 + pt))) {
+                    EMEI_STAT_WAVE(4);
+                    EMEI_STAT_LANE(5);
                     // The geometry of a point does not change during the iteration, so hipcc would hoist all of it (16
                     // points x ~15 doubles) out of the Newton loop and spill ~1 KB per lane to scratch around every
                     // evaluation — measured: 3x the time of the whole solve.  An opaque copy of the link's sin / cos
@@ -704,7 +722,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                             an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
                         }
                     const R mu = (R)kGeom.friction;
-                    const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+                    const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
                     // x_edge = J_edge a - aref_edge, aref_edge = -B (J_edge v) - K imp pos
                     const R xn = an + (R)m.cB * vn + (R)m.cK * imp * dist, xt = mu * (at + (R)m.cB * vt);
                     const R x1 = xn + xt, x2 = xn - xt;
@@ -750,11 +768,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
             contact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
 
-            // converged lanes keep stepping (their steps are ~0) until the whole wave is done
+    EMEI_MARK(nw_conv);
+            // a lane leaves when ITS gradient is down (its result does not depend on its wave-mates); the passes the
+            // slower lanes still need skip every row block none of them has
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
-            if (__ballot(!(gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax)) == 0ull) break;
+            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) break;
+    EMEI_MARK(nw_step);
             ldl_factor(A, invd);
             ldl_forward<0, true>(A, gr);
 #pragma unroll
@@ -763,21 +784,31 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
+    EMEI_MARK(nw_final);
+        EMEI_STAT_LANE(8 + (n_pass < 23 ? n_pass : 23));
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
-        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
+        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a)
             R rhs[NV];
-            build_inertia(A, R(0));
-            sym_matvec(A, a, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) rhs[i] = R(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
+                rhs[jc[k]] += t, rhs[jp[k]] -= t;
+            }
             build_inertia(A, hd);
             ldl_factor(A, invd);
             ldl_forward<0, true>(A, rhs);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] = rhs[i] * invd[i];
-            ldl_backward(A, a);
+            for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
+            ldl_backward(A, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
         }
     }
+    EMEI_MARK(nw_out);
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[P_TORSO];
     qacc[3] = a[P_BTHIGH] - a[P_TORSO], qacc[4] = a[P_BSHIN] - a[P_BTHIGH], qacc[5] = a[P_BFOOT] - a[P_BSHIN];
     qacc[6] = a[P_FTHIGH] - a[P_TORSO], qacc[7] = a[P_FSHIN] - a[P_FTHIGH], qacc[8] = a[P_FFOOT] - a[P_FSHIN];

@@ -229,7 +229,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             R Aii = R(0), acur = R(0);
 #pragma unroll
             for (int i = C; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
-            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+            const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
             const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
             const R Rr = div_r(R(1) - imp, imp) * Aii;
             const R force = div_r(aref - acur, Aii + Rr);
@@ -279,7 +279,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
             }
             const R pos = dist - (R)kGeom.margin;
-            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
             const R k1 = div_r(R(1) - imp, imp);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - an, Ann + k1 * Ann);
             if (fn > R(0)) {
@@ -402,18 +402,11 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         const R ez = fma_r((R)kGeom.geom_end[pt][1], cs[L], -((R)kGeom.geom_end[pt][0] * sn[L]));
         rows |= (org[L].z + ez - (R)kGeom.radius[gi] < (R)kGeom.margin) ? (1u << (3 + pt)) : 0u;
     }
-    // without rows: qacc = (M + h B)^-1 qfrc_smooth, for every lane (results independent of the rest of the wave)
     R A[NV][NV], invd[NV], a[NV];
-    build_inertia(A, hd);
-    ldl_factor(A, invd);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = f[i];
-    ldl_forward<0>(A, a);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-    ldl_backward(A, a);
-    if (rows != 0u) {
-        build_inertia(A, R(0));
+    EMEI_STAT_LANE(0);
+    EMEI_STAT_WAVE(7);
+    if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
+        build_inertia(A, hd);
         ldl_factor(A, invd);
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] = f[i];
@@ -421,9 +414,21 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] *= invd[i];
         ldl_backward(A, a);
+    } else {
+        EMEI_STAT_LANE(1);
+        // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
         if (warm.valid) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
+        } else {
+            build_inertia(A, R(0));
+            ldl_factor(A, invd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] = f[i];
+            ldl_forward<0>(A, a);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+            ldl_backward(A, a);
         }
         R u[NV];
 #pragma unroll
@@ -432,9 +437,13 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         R fmax = R(1);
 #pragma unroll
         for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
+        [[maybe_unused]] int n_pass = 0;
 #pragma unroll 1
         for (int it = 0; it < cheetah::kMaxNewton; ++it) {
             R gr[NV];
+            ++n_pass;
+            EMEI_STAT_LANE(2);
+            EMEI_STAT_WAVE(3);
             build_inertia(A, R(0));
             sym_matvec(A, a, gr);
 #pragma unroll
@@ -442,10 +451,11 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             auto limit = [&](auto kc) __attribute__((always_inline)) {  // theta_k = phi_P - phi_C: J = +-(e_P - e_C)
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
+                    EMEI_STAT_WAVE(6);
                     const R th = q[3 + k];
                     const bool lower = th < (R)kGeom.lo[k];
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
-                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)kGeom.l_width);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
                     const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
                     const R x = J * (a[P] - a[C]) - aref;
                     if (x < R(0)) {
@@ -460,6 +470,8 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             auto contact = [&](auto pt_c) __attribute__((always_inline)) {
                 constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
                 if (rows & (1u << (3 + pt))) {
+                    EMEI_STAT_WAVE(4);
+                    EMEI_STAT_LANE(5);
                     R csl = cs[LNK], snl = sn[LNK];  // opaque: keeps the point's geometry inside the loop (cheetah_model.h)
                     asm volatile("" : "+v"(csl), "+v"(snl));
                     const V2<R> e = rot(csl, snl, (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
@@ -481,7 +493,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     constexpr double mu_c = kGeom.friction[gi];
                     const R mu = (R)mu_c;
                     const R pos = dist - (R)kGeom.margin;
-                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)kGeom.c_width);
+                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
                     const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
                     const R x1 = xn + xt, x2 = xn - xt;
                     const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
@@ -507,7 +519,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
-            if (__ballot(!(gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax)) == 0ull) break;
+            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) break;  // per lane, as in cheetah_model.h
             ldl_factor(A, invd);
             ldl_forward<0>(A, gr);
 #pragma unroll
@@ -516,19 +528,27 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
+        EMEI_STAT_LANE(8 + (n_pass < 23 ? n_pass : 23));
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
-        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a
+        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a)
             R rhs[NV];
-            build_inertia(A, R(0));
-            sym_matvec(A, a, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) rhs[i] = R(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
+                rhs[jc[k]] += t, rhs[jp[k]] -= t;
+            }
             build_inertia(A, hd);
             ldl_factor(A, invd);
             ldl_forward<0>(A, rhs);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] = rhs[i] * invd[i];
-            ldl_backward(A, a);
+            for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
+            ldl_backward(A, rhs);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
         }
     }
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[L_TORSO];

@@ -132,6 +132,41 @@ def test_abi_library_exports_every_declared_symbol():
     assert {s for s in exported if s.startswith("emei_")} == declared  # nothing undeclared leaks out either
 
 
+def test_create_rejects_bad_configs_before_touching_a_device():
+    """Argument validation of emei_create happens on the host, ahead of any HIP call: sizes the kernels' 32-bit env index
+    cannot address, an unknown solver / integrator / precision, negative sigmas.  (No GPU needed: nothing is launched.)"""
+    lib = _lib.lib()
+
+    def create(**kw):
+        cfg = _lib.EmeiConfig()
+        cfg.struct_size = C.sizeof(_lib.EmeiConfig)
+        cfg.env_id, cfg.n_envs, cfg.freq_rate, cfg.real_time_scale = _lib.ENV_IDS["HalfCheetahRunning"], 64, 1, 0.02
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.emei_create(C.byref(cfg), C.byref(h))
+        assert not h.value
+        return rc, lib.emei_last_error().decode()
+
+    for bad in (0, -5, 1 << 31, 1 << 40):
+        rc, msg = create(n_envs=bad)
+        assert rc == _lib.ERR_INVALID and "n_envs" in msg, (bad, msg)
+    assert create(solver=2) == (_lib.ERR_INVALID, "emei_create: solver=2")
+    assert create(integrator=3)[0] == _lib.ERR_UNSUPPORTED  # mujoco_env.py:78-79 raises NotImplementedError
+    assert create(precision=7)[0] == _lib.ERR_INVALID
+    assert create(freq_rate=0)[0] == _lib.ERR_INVALID
+    assert create(real_time_scale=0.0)[0] == _lib.ERR_INVALID
+    assert create(real_time_scale=float("nan"))[0] == _lib.ERR_INVALID
+    assert create(noise_layout=2)[0] == _lib.ERR_INVALID
+    assert create(env_id=99)[0] == _lib.ERR_INVALID
+    assert create(env_param_mask=1 << 8)[0] == _lib.ERR_INVALID
+    assert create(env_param_mask=1 << 2)[0] == _lib.ERR_INVALID  # HalfCheetah has only the two reward weights
+    assert create(env_id=_lib.ENV_IDS["CartPoleSwingUp"], env_param_mask=1)[0] == _lib.ERR_UNSUPPORTED
+    sig = (C.c_float * 32)(*([0.0] * 32))
+    sig[3] = -1e-3
+    assert create(init_sigma=sig)[0] == _lib.ERR_INVALID
+
+
 def test_no_product_import_of_the_oracle():
     """The product package must never reach into oracle/ (it is test infrastructure)."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "emei_amd")):
