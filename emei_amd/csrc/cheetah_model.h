@@ -672,11 +672,16 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
                     EMEI_STAT_WAVE(6);
-                    const R th = q[3 + k];
+                    // opaque, as the contact rows below: a violated limit is rare (0.15 rows per pass of a wave in config 4),
+                    // but its impedance / reference terms do not depend on the iterate, so hipcc would compute them for all
+                    // limits of every evaluation ahead of the loop (~30 instructions each, two divisions; A/B on one box:
+                    // 10.9 vs 11.25 ms per 100 steps of config 4)
+                    R th = q[3 + k], vk = v[3 + k];
+                    asm volatile("" : "+v"(th), "+v"(vk));
                     const bool lower = th < (R)kGeom.lo[k];
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
                     const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
-                    const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+                    const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
                     const R x = J * (a[C] - a[P]) - aref;
                     if (x < R(0)) {
                         const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);  // 1 / R

@@ -452,11 +452,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
                     EMEI_STAT_WAVE(6);
-                    const R th = q[3 + k];
+                    // NOT opaque (cheetah_model.h makes its limit rows so): the hopper sits at a joint limit most of the time
+                    // (2.5 limit rows per pass of a wave, tools/newton_stats.py), and the impedance / reference terms hipcc
+                    // computes once ahead of the loop are then cheaper than per pass (A/B on one box: 30.1 vs 32.7 ms)
+                    const R th = q[3 + k], vk = v[3 + k];
                     const bool lower = th < (R)kGeom.lo[k];
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
                     const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
-                    const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+                    const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
                     const R x = J * (a[P] - a[C]) - aref;
                     if (x < R(0)) {
                         const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);
@@ -472,8 +475,11 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 if (rows & (1u << (3 + pt))) {
                     EMEI_STAT_WAVE(4);
                     EMEI_STAT_LANE(5);
-                    R csl = cs[LNK], snl = sn[LNK];  // opaque: keeps the point's geometry inside the loop (cheetah_model.h)
-                    asm volatile("" : "+v"(csl), "+v"(snl));
+                    // The point's geometry, impedance and reference terms do not depend on the iterate: hipcc computes them
+                    // once ahead of the loop.  Right for this body — most of its 8 points are in contact (5.4 row blocks per
+                    // pass of a wave) and their ~40 doubles fit the register file (386 VGPRs, no scratch): 25.7 vs 30.3 ms per
+                    // 100 RK4 steps against recomputing per pass.  The cheetah (16 points, 2 in contact) does the opposite.
+                    const R csl = cs[LNK], snl = sn[LNK];
                     const V2<R> e = rot(csl, snl, (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
