@@ -1,0 +1,75 @@
+"""bench.py's output contract (the driver parses the ONE JSON line rank 0 prints): required keys, their types, and the
+arithmetic that ties them together — `value` to `ms_per_step`, `roofline.achieved` to the kernel duration and the
+algorithmic bytes per launch, `frac` to achieved / peak.  Run as the driver runs it, in a child process; the N = 2
+launch is rehearsed with the ranks sharing the one GPU over gloo (RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+            "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict,
+            "cpu_baseline": dict}
+
+
+def _line(cmd, env=None, timeout=300):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout: " + p.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def _check_common(j, n_gpus, steps, warmup):
+    for k, t in REQUIRED.items():
+        if k == "cpu_baseline" and n_gpus > 1:
+            continue  # timed on rank 0 at N = 1 only
+        assert k in j, k
+        assert isinstance(j[k], t) or (t is float and isinstance(j[k], int)), (k, type(j[k]))
+    assert "vs_baseline" in j and j["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert (j["metric"], j["unit"], j["higher_is_better"], j["scaling"]) == ("env-steps/s", "env-steps/s", True, "weak")
+    assert (j["n_gpus"], j["steps"], j["warmup"]) == (n_gpus, steps, warmup)
+    assert j["dtype"] == "f64" and "synthetic" in j["data"] and "workload" in j["config"] and "model" not in j["config"]
+    per_pass = j["config"]["env_steps_per_bench_step"]
+    assert per_pass == j["config"]["envs_per_gpu"] * j["config"]["horizon"] * n_gpus
+    assert j["value"] == pytest.approx(per_pass / (j["ms_per_step"] * 1e-3), rel=1e-6)
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0.0 < r["frac"] < 1.0
+    assert r["algorithmic_bytes_per_launch"] == 22 * j["config"]["envs_per_gpu"] * j["config"]["horizon"] // (
+        j["config"]["horizon"] // j["config"]["chunk_steps"])
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert "pend_rollout_staged_kernel" in r["kernel"]
+    assert r["traffic"] is None or "traffic_source" in r
+
+
+def test_default_single_gpu_line():
+    steps, warmup = 5, 2
+    j = _line([sys.executable, "bench.py", "--steps", str(steps), "--warmup", str(warmup)])
+    _check_common(j, 1, steps, warmup)
+    assert "65 536" in j["config"]["workload"] and "configs[1]" in j["config"]["workload"]
+    # the whole timed region is K launches: a pass cannot be faster than its kernel
+    assert j["ms_per_step"] >= j["roofline"]["kernel_ms"] * 0.98
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert j["value"] > 1e7  # north_star's floor
+
+
+def test_two_rank_line_over_gloo_sharing_the_gpu():
+    steps, warmup = 3, 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", "bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup)]
+    j = _line(cmd, env={"EMEI_BENCH_SHARE_GPU": "1", "EMEI_BENCH_BACKEND": "gloo"}, timeout=600)
+    _check_common(j, 2, steps, warmup)
+    cfg = j["config"]
+    assert cfg["envs_per_gpu"] == 131072 and cfg["gather"] == "per_chunk" and cfg["chunk_steps"] == 125
+    x = j["xgmi"]
+    assert x["inbound_bytes_per_rank_per_pass"] == 131072 * 1000 * 16  # one peer's whole [T, n, 4] float32 return
