@@ -110,7 +110,13 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
 #pragma unroll
     for (int i = 0; i < NV; ++i) q[i] = s[i], v[i] = s[NV + i];
     if constexpr (!RK4) {
-        Body::accel(q, v, ctrl, m, dt, acc, trig, warm);
+        // Euler: every evaluation starts cold.  A/B on one box (config 4 / Hopper): 10.1 vs 10.9 ms and 8.0 vs 8.2 ms per
+        // 100 steps — the previous substep's minimiser is no nearer to the new one than the unconstrained acceleration
+        // is (either way a lane needs one step and the pass that confirms it), and carrying it costs registers.  The RK4
+        // stages below DO share it: 25.6 vs 28.9 ms (Hopper), 37.3 vs 41.4 ms (cheetah); resetting it per substep loses half
+        // of that (27.6 / 39.8).
+        typename Body::Warm cold{};
+        Body::accel(q, v, ctrl, m, dt, acc, trig, cold);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const R vn = fma_r(dt, acc[i], v[i]);

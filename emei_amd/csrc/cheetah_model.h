@@ -499,8 +499,8 @@ __device__ __forceinline__ void sym_matvec(const R (&A)[NV][NV], const R (&x)[NV
 // the fill pattern of M (a contact row lives on a root path), so the sparse LDL^T serves it.  Everything is carried in
 // the absolute-angle coordinates of accel(); `hd` > 0: MuJoCo's Euler applies the joint damping implicitly AFTER the
 // solve, (M + h B) qacc = qfrc_smooth + J' f = M a.
-// `warm`: the minimiser of the previous evaluation of the same env-step (substeps, RK4 stages): consecutive states share
-// their active set almost always, and Newton started there needs one step instead of ~5.
+// `warm`: the minimiser of the previous RK4 stage evaluation of the same env-step (body_kernels.h:body_substep; Euler
+// evaluations start cold — measured there): stage states share their active set almost always.
 template <typename R>
 struct NewtonWarm {
     R a[NV];

@@ -329,6 +329,20 @@ def planar_solve(body, q, v, ctrl, dt=0.002, hd=0.0):
     return dict(acc_newton=an, acc_sweep1=a1, nrows=nr.value, iters=it.value, resid=res.value)
 
 
+def planar_solve_unit(body, q, v, ctrl, dt=0.002, warm=None, max_iter=24):
+    """The HIP kernels' iteration restated (unit Newton steps, |g|_inf <= 1e-11 |f|_inf, optional warm start) on one state
+    -> dict(a, passes, nrows); passes == max_iter + 1 means the cap was hit."""
+    nv = 9 if body == "cheetah" else 6
+    q, v, ctrl = (np.ascontiguousarray(x, np.float64) for x in (q, v, ctrl))
+    a = np.empty(nv)
+    w = None if warm is None else np.ascontiguousarray(warm, np.float64)
+    ps, nr = C.c_int(), C.c_int()
+    lib().planar_oracle_solve_unit(C.c_int(0 if body == "cheetah" else 1), C.c_double(dt), _p(q, C.c_double), _p(v, C.c_double),
+                                   _p(ctrl, C.c_double), _p(w, C.c_double) if w is not None else None, C.c_int(max_iter),
+                                   _p(a, C.c_double), C.byref(ps), C.byref(nr))
+    return dict(a=a, passes=ps.value, nrows=nr.value)
+
+
 def planar_invweights(body):
     """(dof_invweight0 [nv], body_invweight0 [nb]) of the planar-tree oracle at qpos0 (mj_setConst)."""
     nv, nb = (9, 7) if body == "cheetah" else (6, 4)

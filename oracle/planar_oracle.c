@@ -410,15 +410,24 @@ static void matvec(int n, const double A[NV][NV], const double* x, double* y) {
 
 /* MuJoCo's constraint solve restated: Newton on the primal cost with an exact line search, to convergence.
  * *iters_out / *resid_out (optional): iterations used and the final scaled gradient norm. */
+/* unit_steps != 0 (diagnostics only, planar_oracle_solve_unit): no line search, alpha = 1 — the iteration the HIP kernels run
+ * (cheetah_model.h:accel_newton), started from `start` when given; stops on the kernels' criterion |g|_inf <= 1e-11 |f|_inf
+ * with fmax passed in `unit_fmax`. */
+static void newton_solve_ex(int nv, const double M[NV][NV], const double* a0, int nr, const crow_t* rows, double* a, int* iters_out,
+                            double* resid_out, int unit_steps, const double* start, double unit_fmax, int max_iter);
 static void newton_solve(int nv, const double M[NV][NV], const double* a0, int nr, const crow_t* rows, double* a, int* iters_out,
                          double* resid_out) {
+    newton_solve_ex(nv, M, a0, nr, rows, a, iters_out, resid_out, 0, NULL, 0.0, 200);
+}
+static void newton_solve_ex(int nv, const double M[NV][NV], const double* a0, int nr, const crow_t* rows, double* a, int* iters_out,
+                            double* resid_out, int unit_steps, const double* start, double unit_fmax, int max_iter) {
     double scale = 0; /* 1 / (mean inertia * nv), mj_solNewton's scaling of the gradient */
     for (int i = 0; i < nv; ++i) scale += M[i][i];
     scale = 1.0 / scale;
-    memcpy(a, a0, nv * sizeof(double));
+    memcpy(a, start ? start : a0, nv * sizeof(double));
     int it = 0;
     double gn = 0;
-    for (; it < 200; ++it) {
+    for (; it < max_iter; ++it) {
         double H[NV][NV], g[NV], d[NV], da[NV], Mda[NV];
         for (int i = 0; i < nv; ++i) da[i] = a[i] - a0[i];
         matvec(nv, M, da, g);
@@ -435,10 +444,19 @@ static void newton_solve(int nv, const double M[NV][NV], const double* a0, int n
         gn = 0;
         for (int i = 0; i < nv; ++i) gn += g[i] * g[i];
         gn = sqrt(gn) * scale;
-        if (gn < 1e-11) break; /* MuJoCo's own tolerance is 1e-8; the rounding floor of this gradient is ~1e-13 */
+        if (unit_steps) {
+            double gmax = 0;
+            for (int i = 0; i < nv; ++i) gmax = fmax(gmax, fabs(g[i]));
+            gn = gmax / unit_fmax;
+            if (gmax <= 1e-11 * unit_fmax) break;
+        } else if (gn < 1e-11) break; /* MuJoCo's own tolerance is 1e-8; the rounding floor of this gradient is ~1e-13 */
         ldl_factor(nv, H);
         for (int i = 0; i < nv; ++i) d[i] = -g[i];
         ldl_solve(nv, H, d);
+        if (unit_steps) {
+            for (int i = 0; i < nv; ++i) a[i] += d[i];
+            continue;
+        }
         /* exact line search: phi'(alpha) = d.M (a + alpha d - a0) + sum_active D (x_r + alpha jd_r) jd_r is piecewise linear
          * and increasing; Newton on it from alpha = 1 (the minimiser when the active set does not change), bisection guard */
         matvec(nv, M, d, Mda);
@@ -717,6 +735,36 @@ EXPORT void planar_oracle_solve(int body, double dt, double hd, const double* q,
     planar_accel_newton(&m, dt, hd, q, v, ctrl, a, iters, resid, nrows);
     if (acc_newton) memcpy(acc_newton, a, m.nv * sizeof(double));
     if (acc_sweep1) planar_accel_sweep1(&m, dt, hd, q, v, ctrl, acc_sweep1);
+}
+/* diagnostics: the kernels' iteration (unit Newton steps, their stopping rule, optional warm start = the minimiser of a
+ * previous evaluation) on one state -> the minimiser `a` (before the Euler damping step), *passes = gradient evaluations used
+ * (the kernels' pass count; max_iter + 1 if the cap was hit), *nrows. */
+EXPORT void planar_oracle_solve_unit(int body, double dt, const double* q, const double* v, const double* ctrl, const double* warm,
+                                     int max_iter, double* a_out, int* passes, int* nrows) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    const int nv = m.nv;
+    kin_t k;
+    kinematics(&m, q, &k);
+    double M[NV][NV], L[NV][NV], f[NV], a0[NV];
+    smooth_terms(&m, &k, q, v, ctrl, M, f);
+    memcpy(L, M, sizeof(L));
+    ldl_factor(nv, L);
+    memcpy(a0, f, nv * sizeof(double));
+    ldl_solve(nv, L, a0);
+    crow_t rows[MAXROWS];
+    const int nr = build_rows(&m, &k, dt, q, v, rows);
+    *nrows = nr;
+    if (nr == 0) {
+        memcpy(a_out, a0, nv * sizeof(double));
+        *passes = 0;
+        return;
+    }
+    double fm = 1.0;
+    for (int i = 0; i < nv; ++i) fm = fmax(fm, fabs(f[i]));
+    int it = 0;
+    newton_solve_ex(nv, M, a0, nr, rows, a_out, &it, NULL, 1, warm, fm, max_iter);
+    *passes = it + 1;
 }
 EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
     planar_model_t m;
