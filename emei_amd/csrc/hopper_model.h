@@ -570,7 +570,7 @@ struct HopperBody {
     using Model = hopper::Model;
     // single sweep: the 256-register cap buys a second resident wave; the Newton solve needs the whole file
     static constexpr int kMinWavesPerEU = SOLVER == EMEI_SOLVER_SWEEP1 ? 2 : 1;
-    static constexpr bool kUnrollRK4 = false;
+    static constexpr bool kUnrollRK4 = false;  // unrolled: the same time with the Newton solver (25.76 vs 25.73 ms), 4x the code
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 12, NO = 12, NA = 3;
