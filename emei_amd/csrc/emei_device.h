@@ -177,8 +177,11 @@ __device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, dou
     const double magic = 6755399441055744.0;
     const double shifted = __builtin_fma(x, inv_step, magic);
     const double n = shifted - magic;
-    // table index from the low mantissa bits: (k & 255) * 16 + base, two instructions (v_and_b32, v_lshl_add_u32)
-    const uint32_t addr = (((uint32_t)__double2loint(shifted) & (uint32_t)(kTrigTableSize - 1)) << 4) + t.lds_base;
+    // table index from the low mantissa bits: (k & 255) * 16 + base in two instructions, written out because hipcc turns
+    // the C expression into three (shift, mask with 0xff0, add)
+    static_assert(kTrigTableSize == 256, "the index mask below");
+    uint32_t addr;
+    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, 4, %2" : "=v"(addr) : "v"((uint32_t)__double2loint(shifted)), "s"(t.lds_base));
     asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
     double r = __builtin_fma(-n, H1, x);
     r = __builtin_fma(-n, H2, r);
