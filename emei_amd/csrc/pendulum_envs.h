@@ -270,21 +270,32 @@ struct InvPend {
         // range -2 2): the violated side, if any, is the one x is on, and its distance is x_hi - |x|.
         static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
         const R dist = (R)m.x_hi - fabs(x_old);
+        EMEI_STAT_WAVE(19);  // substeps (waves)
         if (dist < R(0)) {
+            EMEI_STAT_WAVE(20);  // ... with the limit block
+            EMEI_STAT_LANE(21);  // lanes beyond the rail
             const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one
             const R A = (R)m.M22 * idet;                           // J M^-1 J^T
             // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost
             // always — then the wave skips the polynomial)
-            R imp = (R)m.dmax;
+            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw): one division.
+            // The same expression in both branches, so that a lane's bits do not depend on the branch its WAVE took (with
+            // y = 1 the polynomial branch gives imp == dmax exactly); with the constant, -limK imp and (1 - imp) invw leave
+            // the substep loop.
+            auto force_of = [&](R imp) __attribute__((always_inline)) {
+                const R aref = fma_r(-(R)p.limK * imp, dist, -(R)p.limB * flip_sign(v_old, jm));
+                return (aref - flip_sign(a0, jm)) * imp * rcp1_r(fma_r(A, imp, (R(1) - imp) * (R)m.invw));
+            };
+            static_assert(0.9 + (0.95 - 0.9) == 0.95 && m.dmin == 0.9 && m.dmax == 0.95, "imp(y = 1) == dmax bit for bit");
             const R xx = -dist * (R)m.inv_width;
+            R force;
             if (__builtin_expect(__ballot(xx < R(1)) != 0ull, 0)) {
                 const R u1 = R(1) - xx;
                 const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
-                imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+                force = force_of(fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin));
+            } else {
+                force = force_of((R)m.dmax);
             }
-            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw): one division
-            const R aref = fma_r(-(R)p.limK * imp, dist, -(R)p.limB * flip_sign(v_old, jm));
-            const R force = (aref - flip_sign(a0, jm)) * imp * rcp1_r(fma_r(A, imp, (R(1) - imp) * (R)m.invw));
             if (force > R(0)) {
                 const R Jf = flip_sign(force, jm);
                 a0 = fma_r(A, Jf, a0);

@@ -227,8 +227,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     bool have_spare = false;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         // cold: laid out of line so that the usual case falls through
+        EMEI_STAT_WAVE(16);  // staged-kernel event counters of a -DEMEI_NEWTON_STATS build (tools/pend_stats.py): env-steps (waves)
         if (__builtin_expect((__ballot(done != 0) & reset_mask) != 0ull, 0)) {  // scalar test: no vector instruction
+            EMEI_STAT_WAVE(17);  // ... steps in which some lane resets
             if (__ballot((done != 0) & !have_spare) != 0ull) {
+                EMEI_STAT_WAVE(18);  // ... spare refills
                 if (!have_spare) {
                     typename Env::Carry sc;
                     sc.trig = c.trig;

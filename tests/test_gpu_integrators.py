@@ -105,7 +105,7 @@ def test_obs_noise_draw_for_draw_vs_oracle(body, layout):
         obs, rew, done = eng.step(torch.as_tensor(act32, device=eng.device))
         st, o_obs, o_rew, _ = ostep(st, act32.astype(np.float64), fr, dt,
                                     O.opts("rk4", obs_noise=sig, shared=layout == "shared", seed=21, env_offset=1000, step_index=t))
-        assert rel_err(eng.get_state().cpu().numpy(), st, floor=1.0) <= 1e-6, (body, layout, t)  # float32 Box-Muller, libm vs device
+        assert rel_err(eng.get_state().cpu().numpy(), st, floor=1.0) <= 1e-6, (body, layout, t)  # float32 Box-Muller: exact value (oracle) vs hardware transcendentals (device)
         st = eng.get_state().cpu().numpy()  # re-synchronise
     clean = _engine(name, n, freq_rate=fr, real_time_scale=dt, integrator="rk4")
     clean.set_state(s0)
@@ -158,7 +158,8 @@ def test_init_layouts_on_device():
                 base[1] = 1.25
             for e in (0, 5, 511):
                 want = O.body_init(4, 50 + e, 0, nv, 0.1, 0.2, shared=layout == "shared") + base
-                assert rel_err(s[e], want, floor=1e-2) <= 1e-5, (name, layout, e)
+                # exact Box-Muller (oracle) vs the hardware float32 transcendentals: |dz| <= ~1.2e-6 (tools/bm_accuracy.hip)
+                assert np.abs(s[e] - want).max() <= 0.2 * 1.5e-6, (name, layout, e)
             if layout == "shared":
                 assert np.allclose(s[:, :nv] - base[:nv], (s[:, :1] - base[0]), atol=1e-12)
 

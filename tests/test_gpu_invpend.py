@@ -135,7 +135,9 @@ def test_device_reset_matches_oracle_spec():
     eng.reset(21)
     got = eng.get_state().cpu().numpy()
     want = np.stack([O.ip_init_f32(21, 77 + i, 0, 5e-3) for i in range(512)]).astype(np.float64)
-    assert np.abs(got - want).max() <= 5e-9  # Box-Muller through different libm's: a few float32 ulp of 5e-3
+    # the oracle holds the exact Box-Muller value; the device's hardware sin / cos / log2 / sqrt are within 1.3e-7 and 4.9e-7
+    # of it (tools/bm_accuracy.hip, all 2^24 inputs): |dz| <= 4 * 1.3e-7 + 4.9e-7 ~ 1e-6 at radius 4, times sigma = 5e-3
+    assert np.abs(got - want).max() <= 1e-8
 
 
 def test_full_size_config3_properties():
