@@ -630,7 +630,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         for (int i = 0; i < NV; ++i) a[i] *= invd[i];
         ldl_backward(A, a);
     } else {
-    EMEI_MARK(nw_smooth0);
+        EMEI_MARK(nw_smooth0);
         EMEI_STAT_LANE(1);
         // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
         if (warm.valid) {
@@ -657,7 +657,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         [[maybe_unused]] int n_pass = 0;
 #pragma unroll 1
         for (int it = 0; it < kMaxNewton; ++it) {
-    EMEI_MARK(nw_pass_base);
+            EMEI_MARK(nw_pass_base);
             R gr[NV];
             ++n_pass;
             EMEI_STAT_LANE(2);
@@ -666,7 +666,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             sym_matvec(A, a, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gr[i] -= f[i];
-    EMEI_MARK(nw_limits);
+            EMEI_MARK(nw_limits);
             // joint-limit rows
             auto limit = [&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
@@ -694,7 +694,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             };
             limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
             limit(std::integral_constant<int, 3>{}), limit(std::integral_constant<int, 4>{}), limit(std::integral_constant<int, 5>{});
-    EMEI_MARK(nw_contacts);
+            EMEI_MARK(nw_contacts);
             // contact rows: the four edges of the pyramid of one capsule end sphere
             auto contact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
                                __attribute__((always_inline)) {
@@ -773,14 +773,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
             contact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
 
-    EMEI_MARK(nw_conv);
+            EMEI_MARK(nw_conv);
             // a lane leaves when ITS gradient is down (its result does not depend on its wave-mates); the passes the
             // slower lanes still need skip every row block none of them has
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
             if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) break;
-    EMEI_MARK(nw_step);
+            EMEI_MARK(nw_step);
             ldl_factor(A, invd);
             ldl_forward<0, true>(A, gr);
 #pragma unroll
@@ -789,7 +789,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
-    EMEI_MARK(nw_final);
+        EMEI_MARK(nw_final);
         EMEI_STAT_LANE(8 + (n_pass < 23 ? n_pass : 23));
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];

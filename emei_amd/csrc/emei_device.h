@@ -11,24 +11,29 @@ namespace emei {
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 constexpr int kWave = 64;
 
-// Region markers for tools/isa_regions.py (a comment line in the ISA; nothing in a normal build): the tool compiles a
-// translation unit with -DEMEI_ISA_MARKS and counts the vector instructions between consecutive marks.
-// Solver statistics for tools/newton_stats.py (a variant build with -DEMEI_NEWTON_STATS only; nothing in a normal build):
-// counters per translation unit, read back through emei_debug_stats_<tu>() of body_tu.hip.
+// Device event counters for tools/newton_stats.py and tools/pend_stats.py (a variant build with -DEMEI_NEWTON_STATS only;
+// nothing in a normal build): one array per translation unit, read back through emei_debug_stats_<tu>() of body_tu.hip /
+// pendulum_tu.hip.  Newton solve (cheetah_model.h, hopper_model.h):
 //   0 evaluations (lanes)   1 evaluations with rows (lanes)   2 Newton passes (lanes)   3 Newton passes (waves)
 //   4 contact-row blocks executed (waves)   5 contact-row blocks (lanes)   6 limit-row blocks (waves)   7 evaluations (waves)
+//   8 + k: lane evaluations that took k passes (k >= 23 in the last bin)
+// staged pendulum kernels (pendulum_kernels.h, pendulum_envs.h):
+//   16 env-steps (waves)   17 ... in which some lane resets   18 ... in which spares are redrawn
+//   19 substeps (waves)   20 ... that run the slider-limit block   21 lanes beyond the rail
 #ifdef EMEI_NEWTON_STATS
-static __device__ unsigned long long g_newton_stats[32];  // 8.. : histogram of Newton passes per lane evaluation (8 + min(passes, 23))
-#define EMEI_STAT_LANE(i) atomicAdd(&emei::g_newton_stats[i], 1ull)
+static __device__ unsigned long long g_debug_stats[32];
+#define EMEI_STAT_LANE(i) atomicAdd(&emei::g_debug_stats[i], 1ull)
 #define EMEI_STAT_WAVE(i)                                                                                          \
     do {                                                                                                           \
-        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&emei::g_newton_stats[i], 1ull); \
+        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&emei::g_debug_stats[i], 1ull); \
     } while (0)
 #else
 #define EMEI_STAT_LANE(i) ((void)0)
 #define EMEI_STAT_WAVE(i) ((void)0)
 #endif
 
+// Region markers for tools/isa_regions.py (a comment line in the ISA; nothing in a normal build): the tool compiles a
+// translation unit with -DEMEI_ISA_MARKS and counts the vector instructions between consecutive marks.
 #ifdef EMEI_ISA_MARKS
 #define EMEI_MARK(name) asm volatile("; EMEI_MARK " #name)
 #else

@@ -13,8 +13,8 @@ int EMEI_TU_NAME(const PendLaunch& L) { return launch_env<EMEI_TU_FAMILY<EMEI_TU
 #define EMEI_CAT(a, b) EMEI_CAT2(a, b)
 extern "C" __attribute__((visibility("default"))) int EMEI_CAT(emei_debug_stats_, EMEI_TU_NAME)(unsigned long long* out) {
     unsigned long long zero[32] = {0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(emei::g_newton_stats), sizeof(zero)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(emei::g_newton_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(emei::g_debug_stats), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(emei::g_debug_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
 
