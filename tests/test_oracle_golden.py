@@ -103,3 +103,19 @@ def test_device_reset_distribution():
     assert (np.abs(s) <= 0.05 + 1e-6).all() and abs(s.mean()) < 2e-3 and s.std() == pytest.approx(0.1 / 12**0.5, rel=0.05)
     z = np.stack([O.ip_init_f32(3, e, 0, 1.0) for e in range(4096)])
     assert abs(z.mean()) < 0.05 and z.std() == pytest.approx(1.0, rel=0.05)
+
+
+def test_gaussian_draws_follow_the_stated_box_muller_spec():
+    """oracle/integrators.h: z = sqrt(-2 ln u1) (cos, sin)(2 pi t), u1 = ((a >> 8) + 1) / 2^24, t = (b >> 8) / 2^24 from the
+    Philox words (a, b), (c, d) of block 0 — the exact value rounded once to float32.  Restated here in NumPy float64 from
+    the Philox known-answer-tested words; the device's hardware transcendentals are held to this value on the GPU
+    (test_gpu_invpend.py::test_device_reset_matches_oracle_spec)."""
+    for seed, env, epi in ((3, 0, 0), (21, 77, 0), (2**40 + 5, 2**33 + 1, 7)):
+        w = [int(x) for x in O.philox(seed, env, epi, 0)]
+        want = []
+        for a, b in ((w[0], w[1]), (w[2], w[3])):
+            u1, t = ((a >> 8) + 1.0) / 2**24, (b >> 8) / 2**24
+            rad = np.sqrt(-2.0 * np.log(u1))
+            want += [np.float32(rad * np.cos(2 * np.pi * t)), np.float32(rad * np.sin(2 * np.pi * t))]
+        got = O.ip_init_f32(seed, env, epi, 1.0)  # sigma = 1: the four normals themselves (x, theta, v, omega)
+        assert np.array_equal(np.asarray(got, np.float32), np.asarray(want, np.float32)), (seed, env, epi, got, want)
