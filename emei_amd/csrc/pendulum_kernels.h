@@ -224,15 +224,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     // pure function of (seed, global env, episode), so results do not depend on when it is computed.
     R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);  // dead outside the redraw when the spare lives in LDS
     const unsigned long long reset_mask = auto_reset ? ~0ull : 0ull;
-    bool have_spare = false;
+    // which lanes hold a spare: a wave-uniform 64-bit mask in scalar registers (ballot results and scalar logic only), so
+    // that the bookkeeping of a reset costs no vector instruction; `inverse_ballot` turns it back into a lane predicate
+    unsigned long long spare_mask = 0ull;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
-        // cold: laid out of line so that the usual case falls through
         EMEI_STAT_WAVE(16);  // staged-kernel event counters of a -DEMEI_NEWTON_STATS build (tools/pend_stats.py): env-steps (waves)
-        if (__builtin_expect((__ballot(done != 0) & reset_mask) != 0ull, 0)) {  // scalar test: no vector instruction
+        const unsigned long long done_mask = __ballot(done != 0) & reset_mask;
+        // cold: laid out of line so that the usual case falls through
+        if (__builtin_expect(done_mask != 0ull, 0)) {  // scalar test: no vector instruction
             EMEI_STAT_WAVE(17);  // ... steps in which some lane resets
-            if (__ballot((done != 0) & !have_spare) != 0ull) {
+            if ((done_mask & ~spare_mask) != 0ull) {  // a resetting lane has no spare: redraw for every lane without one
                 EMEI_STAT_WAVE(18);  // ... spare refills
-                if (!have_spare) {
+                if (__builtin_amdgcn_inverse_ballot_w64(~spare_mask)) {
                     typename Env::Carry sc;
                     sc.trig = c.trig;
                     Env::init(sp, a.seed, a.env_offset + (uint64_t)i, episode + 1u, a.p);
@@ -243,10 +246,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                     } else {
                         sp_sn = sc.sn, sp_cs = sc.cs;
                     }
-                    have_spare = true;
                 }
+                spare_mask = ~0ull;
             }
-            if (done != 0) {
+            if (__builtin_amdgcn_inverse_ballot_w64(done_mask)) {
                 ++episode;
                 steps = 0;
                 if constexpr (kLdsSpare) {  // a lane only ever reads what it wrote itself: no fence
@@ -257,8 +260,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                     for (int k = 0; k < 4; ++k) s[k] = sp[k];
                     c.sn = sp_sn, c.cs = sp_cs;
                 }
-                have_spare = false;
             }
+            spare_mask &= ~done_mask;
         }
     };
     // per-lane element offsets inside a flushed block of rows, computed once (the per-step address
