@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""One-off parity sweep of the Newton constraint solve at scale (run on the GPU box; the oracle runs on the host cores):
+N random rough states per body — flight, deep contact, joints past their limits, velocities up to 5x the tests' — one
+env-step on the GPU against the oracle (exact line search), float64.  Prints the worst scaled difference and how many
+states exceed the tests' 1e-9.  Usage: python tools/newton_parity_sweep.py [n_states=200000]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from emei_amd.engine import Engine  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+rng = np.random.default_rng(2024)
+for body, name, nv, nu, step in (("cheetah", "HalfCheetahRunning", 9, 6, O.cheetah_step), ("hopper", "HopperRunning", 6, 3, O.hopper_step)):
+    q = rng.normal(0, 0.25, (n, nv))
+    q[:, 1] = rng.uniform(-0.45, 0.3, n) if body == "cheetah" else 1.25 + rng.uniform(-0.4, 0.1, n)
+    q[: n // 4, 3:] = rng.uniform(-1.5, 1.5, (n // 4, nv - 3))
+    v = rng.normal(0, 2.0, (n, nv)) * np.where(np.arange(n) % 3 == 0, 5.0, 1.0)[:, None]
+    s0 = np.concatenate([q, v], axis=1)
+    act = rng.uniform(-1.3, 1.3, (n, nu)).astype(np.float32)
+    for integ, fr in (("euler", 1), ("rk4", 2)):
+        eng = Engine(name, n, freq_rate=fr, real_time_scale=0.002, precision="ref", integrator=integ, solver="newton")
+        eng.set_state(s0)
+        eng.step(torch.as_tensor(act, device=eng.device))
+        got = eng.get_state().cpu().numpy()
+        want = step(s0, act.astype(np.float64), fr, 0.002, O.opts(integ, solver="newton"))[0]
+        err = np.abs(got - want).max(axis=1) / np.maximum(1.0, np.abs(want).max(axis=1))
+        bad = int((err > 1e-9).sum())
+        print(f"{body} {integ} freq_rate={fr}: {n} states, worst scaled difference {err.max():.2e}, {bad} above 1e-9, "
+              f"non-finite {int((~np.isfinite(got)).any(axis=1).sum())}", flush=True)
+        eng.close()
