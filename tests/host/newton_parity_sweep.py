@@ -2,7 +2,7 @@
 """One-off parity sweep of the Newton constraint solve at scale (run on the GPU box; the oracle runs on the host cores):
 N random rough states per body — flight, deep contact, joints past their limits, velocities up to 5x the tests' — one
 env-step on the GPU against the oracle (exact line search), float64.  Prints the worst scaled difference and how many
-states exceed the tests' 1e-9.  Usage: python tools/newton_parity_sweep.py [n_states=200000]"""
+states exceed the tests' 1e-9.  Usage: python tests/host/newton_parity_sweep.py [n_states=200000]"""
 import sys
 
 import numpy as np

@@ -3,7 +3,7 @@
 through emei_rollout (so that pend_rollout_staged_kernel runs — asserted), against the C oracle stepped the same way.
 CartPole (the pinned oracle): 16 steps, uint8 actions, both variants, freq_rate 1 and 4: float32 observations to 1e-5,
 terminal masks bit for bit.  InvertedPendulum (config 3's kernel): 8 steps x 4 substeps, states on and beyond the rail,
-float64 final state to 1e-9.  Usage: python tools/staged_parity_sweep.py [n=1048576]"""
+float64 final state to 1e-9.  Usage: python tests/host/staged_parity_sweep.py [n=1048576]"""
 import sys
 
 import numpy as np

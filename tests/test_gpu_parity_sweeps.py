@@ -1,4 +1,4 @@
-"""The at-scale parity sweeps (tools/staged_parity_sweep.py, tools/newton_parity_sweep.py) as tests, at a quarter of the
+"""The at-scale parity sweeps (tests/host/staged_parity_sweep.py, tests/host/newton_parity_sweep.py) as tests, at a quarter of the
 size of the recorded runs (profiles/r02_*_parity_sweep.txt): hundreds of thousands of random states per kernel instead of
 the ~1000 of the per-kernel tests, same tolerances."""
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(script, n):
-    p = subprocess.run([sys.executable, os.path.join("tools", script), str(n)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join("tests", "host", script), str(n)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     return [l for l in p.stdout.splitlines() if "difference" in l]
 

@@ -168,12 +168,14 @@ def test_create_rejects_bad_configs_before_touching_a_device():
 
 
 def test_no_product_import_of_the_oracle():
-    """The product package must never reach into oracle/ (it is test infrastructure)."""
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "emei_amd")):
-        for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in txt and "from oracle" not in txt and "libemei_oracle" not in txt, f
+    """The product package must never reach into oracle/ (it is test infrastructure); neither do the developer tools —
+    scripts that check against the oracle live under tests/host/."""
+    for top in ("emei_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert "import oracle" not in txt and "from oracle" not in txt and "libemei_oracle" not in txt, (top, f)
 
 
 def test_product_fails_loudly_without_gpu():
