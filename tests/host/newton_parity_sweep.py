@@ -32,3 +32,18 @@ for body, name, nv, nu, step in (("cheetah", "HalfCheetahRunning", 9, 6, O.cheet
         print(f"{body} {integ} freq_rate={fr}: {n} states, worst scaled difference {err.max():.2e}, {bad} above 1e-9, "
               f"non-finite {int((~np.isfinite(got)).any(axis=1).sum())}", flush=True)
         eng.close()
+
+# the single-constraint body (InvertedDoublePendulum, body_rollout_kernel): states on and beyond the rail and its margin
+for integ, fr in (("euler", 2), ("rk4", 1)):
+    s0 = np.column_stack([rng.uniform(-3.2, 3.2, n), rng.uniform(-3.5, 3.5, (n, 2)), rng.normal(0, 2, (n, 3))])
+    act = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+    eng = Engine("BoundaryInvertedDoublePendulumSwingUp", n, freq_rate=fr, real_time_scale=0.02, precision="ref", integrator=integ)
+    eng.set_state(s0)
+    eng.step(torch.as_tensor(act[:, None], device=eng.device))
+    got = eng.get_state().cpu().numpy()
+    want = O.dpend_step("boundary_swingup", s0, act.astype(np.float64), fr, 0.02, O.opts(integ))[0]
+    err = np.abs(got - want).max(axis=1) / np.maximum(1.0, np.abs(want).max(axis=1))
+    print(f"dpend {integ} freq_rate={fr}: {n} states, worst scaled difference {err.max():.2e}, {int((err > 1e-9).sum())} above 1e-9, "
+          f"non-finite {int((~np.isfinite(got)).any(axis=1).sum())}", flush=True)
+    eng.close()
+

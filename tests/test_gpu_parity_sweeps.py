@@ -34,6 +34,6 @@ def test_staged_kernels_against_the_oracle_at_scale():
 
 def test_newton_solve_against_the_oracle_at_scale():
     lines = _run("newton_parity_sweep.py", 250000)
-    assert len(lines) == 4, lines
+    assert len(lines) == 6, lines  # cheetah, hopper (Newton) x euler / rk4; double pendulum x euler / rk4
     for l in lines:
         assert " 0 above 1e-9" in l and "non-finite 0" in l, l
