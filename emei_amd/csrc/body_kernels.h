@@ -18,6 +18,7 @@
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
 //   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
 //   kUnrollRK4                                      // RK4 stages as straight-line code (see body_substep)
+//   kScratchPerLane                                 // elements of `real` of block LDS per lane that accel() may use (0: none)
 //
 // Layout: one thread per env, state SoA in HBM ([NS][n] Reals), registers across a rollout.  An env's
 // observation (NO floats) and action (NA floats) are wider than one lane access, so each wave stages
@@ -225,6 +226,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
     stage_trig_table(trig_s, a.trig);  // every thread reaches the barrier: inactive lanes stay in the kernel
     TrigCtx trig;
     trig.tab = trig_s;
+    __shared__ R scratch_s[(Body::kScratchPerLane > 0 ? Body::kScratchPerLane : 1) * (Body::kScratchPerLane > 0 ? kBlock : 1)];
+    if constexpr (Body::kScratchPerLane > 0) trig.scratch = scratch_s;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t n = a.n;
@@ -443,6 +446,8 @@ __global__ void __launch_bounds__(kBlock)
     stage_trig_table(trig_s, trig_tab);
     TrigCtx trig;
     trig.tab = trig_s;
+    __shared__ R scratch_s[(Body::kScratchPerLane > 0 ? Body::kScratchPerLane : 1) * (Body::kScratchPerLane > 0 ? kBlock : 1)];
+    if constexpr (Body::kScratchPerLane > 0) trig.scratch = scratch_s;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     R s[NS], pre[NS], ctrl[NA], rew;

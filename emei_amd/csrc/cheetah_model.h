@@ -196,6 +196,14 @@ __device__ constexpr double kLinkInvWeight0[7] = {0.2437492834901718, 0.12720922
 #ifndef EMEI_MAX_NEWTON
 #define EMEI_MAX_NEWTON 24
 #endif
+// Constraint-space ("dual") form of the same active-set iteration for lanes with at most kDualSlots row blocks (contact
+// points, violated joint limits; accel_newton): slots of kSlotFields values per lane in the block's LDS scratch
+#ifndef EMEI_CHEETAH_DUAL_SLOTS
+#define EMEI_CHEETAH_DUAL_SLOTS 2  // 0: every lane iterates in the primal loop (A/B: 10.1 vs 8.6 ms per 100 steps of config 4)
+#endif
+constexpr int kDualSlots = EMEI_CHEETAH_DUAL_SLOTS;
+constexpr int kSlotFields = 26;  // Yn[9], Yt[9], u0n, u0t, bn, bt, Dw, start un, start ut, mu
+static_assert(kDualSlots == 0 || kDualSlots == 2, "the elimination below is written for two slots");
 constexpr int kMaxNewton = EMEI_MAX_NEWTON;  // iteration cap of accel_newton (the oracle's statistics: <= 9 over 40 000 random states)
 
 // Sparse LDL^T in the permuted order.  L is stored in the strict lower triangle of A, 1/D in invd.
@@ -632,8 +640,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     } else {
         EMEI_MARK(nw_smooth0);
         EMEI_STAT_LANE(1);
-        // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
-        if (warm.valid) {
+        // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth (the dual path always
+        // needs M's factor and qacc_smooth; a previous minimiser then only provides its first active set)
+        const bool dual = kDualSlots > 0 && trig.scratch != nullptr && __popc(rows) <= kDualSlots;
+        if (warm.valid && !dual) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
         } else {
@@ -655,6 +665,189 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
 
         [[maybe_unused]] int n_pass = 0;
+        if (dual) {
+            // ---- The same iteration in constraint space.  With M = L D L' and, per contact point p, Y_p = L^-1 (J_n, J_t)':
+            //   a = a0 - L^-T D^-1 sum_p Y_p g_p,   g_p = W_p (u_p + b_p),   u_q = J_q a = u0_q - sum_p G_qp g_p,   G_qp = Y_q' D^-1 Y_p
+            // where W_p (2x2, from the active pyramid edges) and b_p are what the row blocks of the primal loop below
+            // accumulate into H and the gradient.  For a fixed active set this is the LINEAR system (I + W G) g = W (u0 + b)
+            // of size 2 x slots: a pass costs ~160 instructions instead of ~740 (refactoring the 9x9 H), the iterates are
+            // those of the unit-step Newton iteration (piecewise-quadratic cost: a Newton step IS the minimiser of the
+            // current active set), and it ends when the set reproduces itself.  Y, u0, b live in LDS slots because which
+            // points a lane has is only known at run time.
+            EMEI_STAT_LANE(22);
+            EMEI_STAT_WAVE(23);
+            R* const sl = (R*)trig.scratch + threadIdx.x;
+            auto put = [&](int sidx, int fld, R val) __attribute__((always_inline)) { sl[(sidx * kSlotFields + fld) * kBlock] = val; };
+            auto get = [&](int sidx, int fld) __attribute__((always_inline)) { return sl[(sidx * kSlotFields + fld) * kBlock]; };
+            const R mu = (R)kGeom.friction;
+            int slot = 0;
+            // a violated joint limit is a slot with one direction: J = +-(e_C - e_P), no tangent, mu = 0 and D / 4 (with
+            // mu = 0 the three edge tests below coincide and their weights add up to 4)
+            auto dlimit = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
+                if (rows & (1u << k)) {
+                    const R th = q[3 + k];
+                    const bool lower = th < (R)kGeom.lo[k];
+                    const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
+                    const R aref = -(R)m.lB * (J * v[3 + k]) - (R)m.lK * imp * dist;
+                    R Jn[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Jn[i] = R(0);
+                    Jn[C] = J, Jn[P] = -J;
+                    const R an = J * (a[C] - a[P]), wn = J * (warm.a[C] - warm.a[P]);
+                    ldl_forward<C, false>(A, Jn);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) put(slot, i, in_pat(C, i) ? Jn[i] : R(0)), put(slot, NV + i, R(0));
+                    put(slot, 18, an), put(slot, 19, R(0)), put(slot, 20, -aref), put(slot, 21, R(0));
+                    put(slot, 22, R(0.25) * div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]));
+                    put(slot, 23, warm.valid ? wn : an), put(slot, 24, R(0)), put(slot, 25, R(0));
+                    ++slot;
+                }
+            };
+            dlimit(std::integral_constant<int, 0>{}), dlimit(std::integral_constant<int, 1>{}), dlimit(std::integral_constant<int, 2>{});
+            dlimit(std::integral_constant<int, 3>{}), dlimit(std::integral_constant<int, 4>{}), dlimit(std::integral_constant<int, 5>{});
+            auto dcontact = [&](int pt, auto lnk_c, V2<R> org, int a1, V2<R> v1, int a2, V2<R> v2, int a3, V2<R> v3)
+                                __attribute__((always_inline)) {
+                constexpr int LNK = decltype(lnk_c)::value;
+                if (rows & (1u << (6 + pt))) {
+                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const R dist = org.z + e.z - (R)kGeom.radius;
+                    const V2<R> r = {e.x, R(0.5) * dist - org.z};
+                    R Jx[NV], Jz[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    Jx[LNK] = r.z, Jz[LNK] = -r.x;
+                    if (a1 >= 0) Jx[a1] = v1.z, Jz[a1] = -v1.x;
+                    if (a2 >= 0) Jx[a2] = v2.z, Jz[a2] = -v2.x;
+                    if (a3 >= 0) Jx[a3] = v3.z, Jz[a3] = -v3.x;
+                    R vn = R(0), vt = R(0), an = R(0), at = R(0), wn = R(0), wt = R(0);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+                        if (in_pat(LNK, i)) {
+                            vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+                            an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
+                            wn = fma_r(Jz[i], warm.a[i], wn), wt = fma_r(Jx[i], warm.a[i], wt);
+                        }
+                    const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * kGeom.friction * kGeom.friction * (1.0 + kGeom.friction * kGeom.friction)) *
+                                                (R)kLinkInvWeight0[LNK]);
+                    ldl_forward<LNK, false>(A, Jz);  // Y_n, Y_t
+                    ldl_forward<LNK, false>(A, Jx);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        put(slot, i, in_pat(LNK, i) ? Jz[i] : R(0));
+                        put(slot, NV + i, in_pat(LNK, i) ? Jx[i] : R(0));
+                    }
+                    put(slot, 18, an), put(slot, 19, at);
+                    put(slot, 20, (R)m.cB * vn + (R)m.cK * imp * dist), put(slot, 21, (R)m.cB * vt), put(slot, 22, Dw);
+                    put(slot, 23, warm.valid ? wn : an), put(slot, 24, warm.valid ? wt : at), put(slot, 25, mu);
+                    ++slot;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            {
+                const V2<R> none = {R(0), R(0)};
+                using std::integral_constant;
+                dcontact(0, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+                dcontact(1, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+                dcontact(2, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+                dcontact(3, integral_constant<int, P_TORSO>{}, o_t, -1, none, -1, none, -1, none);
+                dcontact(4, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+                dcontact(5, integral_constant<int, P_BTHIGH>{}, o_bt, P_TORSO, Dtb, -1, none, -1, none);
+                dcontact(6, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+                dcontact(7, integral_constant<int, P_BSHIN>{}, o_bs, P_TORSO, Dtb, P_BTHIGH, Dbt, -1, none);
+                dcontact(8, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+                dcontact(9, integral_constant<int, P_BFOOT>{}, o_bf, P_TORSO, Dtb, P_BTHIGH, Dbt, P_BSHIN, Dbs);
+                dcontact(10, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+                dcontact(11, integral_constant<int, P_FTHIGH>{}, o_ft, P_TORSO, Dtf, -1, none, -1, none);
+                dcontact(12, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+                dcontact(13, integral_constant<int, P_FSHIN>{}, o_fs, P_TORSO, Dtf, P_FTHIGH, Dft, -1, none);
+                dcontact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+                dcontact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
+            }
+            // slot data back (static slot index now); an absent second slot stays all zero: W_1 = 0, g_1 = 0
+            R Y0n[NV], Y0t[NV], Y1n[NV], Y1t[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) Y0n[i] = get(0, i), Y0t[i] = get(0, NV + i), Y1n[i] = R(0), Y1t[i] = R(0);
+            const R u0n0 = get(0, 18), u0t0 = get(0, 19), bn0 = get(0, 20), bt0 = get(0, 21), Dw0 = get(0, 22);
+            const R mu0 = get(0, 25);
+            R un0 = get(0, 23), ut0 = get(0, 24);
+            R u0n1 = R(0), u0t1 = R(0), bn1 = R(0), bt1 = R(0), Dw1 = R(0), un1 = R(0), ut1 = R(0), mu1 = R(0);
+            if (slot > 1) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) Y1n[i] = get(1, i), Y1t[i] = get(1, NV + i);
+                u0n1 = get(1, 18), u0t1 = get(1, 19), bn1 = get(1, 20), bt1 = get(1, 21), Dw1 = get(1, 22);
+                un1 = get(1, 23), ut1 = get(1, 24), mu1 = get(1, 25);
+            }
+            R G00nn = R(0), G00nt = R(0), G00tt = R(0), G11nn = R(0), G11nt = R(0), G11tt = R(0);
+            R G01nn = R(0), G01nt = R(0), G01tn = R(0), G01tt = R(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const R d0n = invd[i] * Y0n[i], d0t = invd[i] * Y0t[i], d1n = invd[i] * Y1n[i], d1t = invd[i] * Y1t[i];
+                G00nn = fma_r(d0n, Y0n[i], G00nn), G00nt = fma_r(d0n, Y0t[i], G00nt), G00tt = fma_r(d0t, Y0t[i], G00tt);
+                G11nn = fma_r(d1n, Y1n[i], G11nn), G11nt = fma_r(d1n, Y1t[i], G11nt), G11tt = fma_r(d1t, Y1t[i], G11tt);
+                G01nn = fma_r(d0n, Y1n[i], G01nn), G01nt = fma_r(d0n, Y1t[i], G01nt);
+                G01tn = fma_r(d0t, Y1n[i], G01tn), G01tt = fma_r(d0t, Y1t[i], G01tt);
+            }
+            R g0n = R(0), g0t = R(0), g1n = R(0), g1t = R(0);
+            uint32_t used = 0xffffffffu;
+#pragma unroll 1
+            for (int it = 0; it < kMaxNewton; ++it) {
+                ++n_pass;
+                EMEI_STAT_LANE(2);
+                EMEI_STAT_WAVE(3);
+                // active pyramid edges at the current iterate (cheetah_model.h, primal row block: x1, x2, xn)
+                const R xn0 = un0 + bn0, xt0 = mu0 * (ut0 + bt0), xn1 = un1 + bn1, xt1 = mu1 * (ut1 + bt1);
+                const bool p0 = xn0 + xt0 < R(0), m0 = xn0 - xt0 < R(0), y0 = xn0 < R(0);
+                const bool p1 = xn1 + xt1 < R(0), m1 = xn1 - xt1 < R(0), y1 = xn1 < R(0);
+                const uint32_t flags = (p0 ? 1u : 0u) | (m0 ? 2u : 0u) | (y0 ? 4u : 0u) | (p1 ? 8u : 0u) | (m1 ? 16u : 0u) | (y1 ? 32u : 0u);
+                if (flags == used) break;  // the set the iterate was computed with reproduces itself: the minimiser
+                used = flags;
+                const R c10 = p0 ? R(1) : R(0), c20 = m0 ? R(1) : R(0), cy0 = y0 ? R(2) : R(0);
+                const R c11 = p1 ? R(1) : R(0), c21 = m1 ? R(1) : R(0), cy1 = y1 ? R(2) : R(0);
+                const R w0nn = Dw0 * (c10 + c20 + cy0), w0nt = Dw0 * mu0 * (c10 - c20), w0tt = Dw0 * mu0 * mu0 * (c10 + c20);
+                const R w1nn = Dw1 * (c11 + c21 + cy1), w1nt = Dw1 * mu1 * (c11 - c21), w1tt = Dw1 * mu1 * mu1 * (c11 + c21);
+                const R s0n = u0n0 + bn0, s0t = u0t0 + bt0, s1n = u0n1 + bn1, s1t = u0t1 + bt1;
+                const R r0n = fma_r(w0nn, s0n, w0nt * s0t), r0t = fma_r(w0nt, s0n, w0tt * s0t);
+                const R r1n = fma_r(w1nn, s1n, w1nt * s1t), r1t = fma_r(w1nt, s1n, w1tt * s1t);
+                // P0 = I + W0 G00 (det >= 1: W0, G00 positive semidefinite), T = P0^-1 W0, y0v = P0^-1 r0
+                const R p00 = R(1) + fma_r(w0nn, G00nn, w0nt * G00nt), p01 = fma_r(w0nn, G00nt, w0nt * G00tt);
+                const R p10 = fma_r(w0nt, G00nn, w0tt * G00nt), p11 = R(1) + fma_r(w0nt, G00nt, w0tt * G00tt);
+                const R id0 = rcp_r(fma_r(p00, p11, -(p01 * p10)));
+                const R t00 = fma_r(p11, w0nn, -(p01 * w0nt)) * id0, t01 = fma_r(p11, w0nt, -(p01 * w0tt)) * id0;
+                const R t10 = fma_r(p00, w0nt, -(p10 * w0nn)) * id0, t11 = fma_r(p00, w0tt, -(p10 * w0nt)) * id0;
+                const R y0n = fma_r(p11, r0n, -(p01 * r0t)) * id0, y0t = fma_r(p00, r0t, -(p10 * r0n)) * id0;
+                // E = T G01, C = G10 E, Q = I + W1 (G11 - C) (det >= 1: G11 - C is a Schur complement)
+                const R e00 = fma_r(t00, G01nn, t01 * G01tn), e01 = fma_r(t00, G01nt, t01 * G01tt);
+                const R e10 = fma_r(t10, G01nn, t11 * G01tn), e11 = fma_r(t10, G01nt, t11 * G01tt);
+                const R h00 = G11nn - fma_r(G01nn, e00, G01tn * e10), h01 = G11nt - fma_r(G01nn, e01, G01tn * e11);
+                const R h10 = G11nt - fma_r(G01nt, e00, G01tt * e10), h11 = G11tt - fma_r(G01nt, e01, G01tt * e11);
+                const R q00 = R(1) + fma_r(w1nn, h00, w1nt * h10), q01 = fma_r(w1nn, h01, w1nt * h11);
+                const R q10 = fma_r(w1nt, h00, w1tt * h10), q11 = R(1) + fma_r(w1nt, h01, w1tt * h11);
+                const R d0 = fma_r(G01nn, y0n, G01tn * y0t), d1 = fma_r(G01nt, y0n, G01tt * y0t);
+                const R k1n = r1n - fma_r(w1nn, d0, w1nt * d1), k1t = r1t - fma_r(w1nt, d0, w1tt * d1);
+                const R id1 = rcp_r(fma_r(q00, q11, -(q01 * q10)));
+                g1n = fma_r(q11, k1n, -(q01 * k1t)) * id1, g1t = fma_r(q00, k1t, -(q10 * k1n)) * id1;
+                g0n = y0n - fma_r(e00, g1n, e01 * g1t), g0t = y0t - fma_r(e10, g1n, e11 * g1t);
+                // u = u0 - G g
+                un0 = u0n0 - (fma_r(G00nn, g0n, G00nt * g0t) + fma_r(G01nn, g1n, G01nt * g1t));
+                ut0 = u0t0 - (fma_r(G00nt, g0n, G00tt * g0t) + fma_r(G01tn, g1n, G01tt * g1t));
+                un1 = u0n1 - (fma_r(G01nn, g0n, G01tn * g0t) + fma_r(G11nn, g1n, G11nt * g1t));
+                ut1 = u0t1 - (fma_r(G01nt, g0n, G01tt * g0t) + fma_r(G11nt, g1n, G11tt * g1t));
+            }
+            // a = a0 - L^-T D^-1 sum_p Y_p g_p
+            R z[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                z[i] = invd[i] * (fma_r(Y0n[i], g0n, Y0t[i] * g0t) + fma_r(Y1n[i], g1n, Y1t[i] * g1t));
+            ldl_backward(A, z);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] -= z[i];
+        } else {
+        EMEI_STAT_LANE(24);
+        EMEI_STAT_WAVE(25);
 #pragma unroll 1
         for (int it = 0; it < kMaxNewton; ++it) {
             EMEI_MARK(nw_pass_base);
@@ -789,8 +982,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
+        }  // primal loop / dual path
         EMEI_MARK(nw_final);
-        EMEI_STAT_LANE(8 + (n_pass < 23 ? n_pass : 23));
+        EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
@@ -833,6 +1027,7 @@ struct CheetahBody {
 #define EMEI_CHEETAH_UNROLL_RK4 1
 #endif
     static constexpr bool kUnrollRK4 = EMEI_CHEETAH_UNROLL_RK4 != 0;
+    static constexpr int kScratchPerLane = SOLVER == EMEI_SOLVER_NEWTON ? cheetah::kDualSlots * cheetah::kSlotFields : 0;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;

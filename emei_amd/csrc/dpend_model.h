@@ -67,6 +67,7 @@ struct DPendBody {
     using Model = dpend::Model;
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kUnrollRK4 = false;
+    static constexpr int kScratchPerLane = 0;
     static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;

@@ -16,7 +16,8 @@ constexpr int kWave = 64;
 // pendulum_tu.hip.  Newton solve (cheetah_model.h, hopper_model.h):
 //   0 evaluations (lanes)   1 evaluations with rows (lanes)   2 Newton passes (lanes)   3 Newton passes (waves)
 //   4 contact-row blocks executed (waves)   5 contact-row blocks (lanes)   6 limit-row blocks (waves)   7 evaluations (waves)
-//   8 + k: lane evaluations that took k passes (k >= 23 in the last bin)
+//   8 + k: lane evaluations that took k passes (k >= 13 in the last bin)
+//   22 / 23 evaluations on the constraint-space path (lanes / waves)   24 / 25 on the primal loop (lanes / waves)
 // staged pendulum kernels (pendulum_kernels.h, pendulum_envs.h):
 //   16 env-steps (waves)   17 ... in which some lane resets   18 ... in which spares are redrawn
 //   19 substeps (waves)   20 ... that run the slider-limit block   21 lanes beyond the rail
@@ -137,6 +138,9 @@ struct TrigCtx {
     // inner Horner step as literals hipcc emits v_mov_b64 + the two-address v_fmac_f64 per evaluation
     double c3, c4;  // -1/6, 1/24
     uint32_t lds_base;  // byte address of `tab` in LDS, wave-uniform (an SGPR)
+    // per-block LDS scratch of the body kernels (Body::kScratchPerLane elements of Body::real per lane, lane-interleaved:
+    // element e of this lane at scratch[e * kBlock + threadIdx.x]); null where a kernel provides none
+    void* scratch = nullptr;
 };
 __device__ __forceinline__ void trig_ctx_init(TrigCtx& t, const SinCosEntry* tab) {
     t.tab = tab;

@@ -534,7 +534,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
-        EMEI_STAT_LANE(8 + (n_pass < 23 ? n_pass : 23));
+        EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
@@ -571,6 +571,7 @@ struct HopperBody {
     // single sweep: the 256-register cap buys a second resident wave; the Newton solve needs the whole file
     static constexpr int kMinWavesPerEU = SOLVER == EMEI_SOLVER_SWEEP1 ? 2 : 1;
     static constexpr bool kUnrollRK4 = false;  // unrolled: the same time with the Newton solver (25.76 vs 25.73 ms), 4x the code
+    static constexpr int kScratchPerLane = 0;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 12, NO = 12, NA = 3;

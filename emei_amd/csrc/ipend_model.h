@@ -63,6 +63,7 @@ struct InvPendBody {
     using Model = ipend::Model;
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kUnrollRK4 = true;
+    static constexpr int kScratchPerLane = 0;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 4, NO = 4, NA = 1;
