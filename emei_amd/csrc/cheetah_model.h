@@ -792,7 +792,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 G01tn = fma_r(d0t, Y1n[i], G01tn), G01tt = fma_r(d0t, Y1t[i], G01tt);
             }
             R g0n = R(0), g0t = R(0), g1n = R(0), g1t = R(0);
-            uint32_t used = 0xffffffffu;
+            // cold start (u = u0): g = 0 is the solution of the empty set, so if no edge is active there, a0 is the minimiser;
+            // from a warm start the first pass always solves
+            uint32_t used = warm.valid ? 0xffffffffu : 0u;
 #pragma unroll 1
             for (int it = 0; it < kMaxNewton; ++it) {
                 ++n_pass;
