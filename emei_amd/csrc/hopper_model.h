@@ -416,6 +416,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         ldl_backward(A, a);
     } else {
         EMEI_STAT_LANE(1);
+#ifdef EMEI_NEWTON_STATS
+        if (__popc(rows) <= 2) {  // how many lanes a two-slot constraint-space path (cheetah_model.h) would serve
+            EMEI_STAT_LANE(22);
+        } else {
+            EMEI_STAT_LANE(24);
+            EMEI_STAT_WAVE(25);
+        }
+#endif
         // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
         if (warm.valid) {
 #pragma unroll
