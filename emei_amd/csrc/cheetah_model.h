@@ -768,6 +768,8 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 dcontact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
             }
             // slot data back (static slot index now); an absent second slot stays all zero: W_1 = 0, g_1 = 0
+            R G00nn = R(0), G00nt = R(0), G00tt = R(0), G11nn = R(0), G11nt = R(0), G11tt = R(0);
+            R G01nn = R(0), G01nt = R(0), G01tn = R(0), G01tt = R(0);
             R Y0n[NV], Y0t[NV], Y1n[NV], Y1t[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) Y0n[i] = get(0, i), Y0t[i] = get(0, NV + i), Y1n[i] = R(0), Y1t[i] = R(0);
@@ -781,8 +783,6 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 u0n1 = get(1, 18), u0t1 = get(1, 19), bn1 = get(1, 20), bt1 = get(1, 21), Dw1 = get(1, 22);
                 un1 = get(1, 23), ut1 = get(1, 24), mu1 = get(1, 25);
             }
-            R G00nn = R(0), G00nt = R(0), G00tt = R(0), G11nn = R(0), G11nt = R(0), G11tt = R(0);
-            R G01nn = R(0), G01nt = R(0), G01tn = R(0), G01tt = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const R d0n = invd[i] * Y0n[i], d0t = invd[i] * Y0t[i], d1n = invd[i] * Y1n[i], d1t = invd[i] * Y1t[i];
@@ -839,11 +839,16 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 un1 = u0n1 - (fma_r(G01nn, g0n, G01tn * g0t) + fma_r(G11nn, g1n, G11nt * g1t));
                 ut1 = u0t1 - (fma_r(G01nt, g0n, G01tt * g0t) + fma_r(G11nt, g1n, G11tt * g1t));
             }
-            // a = a0 - L^-T D^-1 sum_p Y_p g_p
+            // a = a0 - L^-T D^-1 sum_p Y_p g_p (Y read again from the slots: 36 values are not worth holding through the loop)
             R z[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                z[i] = invd[i] * (fma_r(Y0n[i], g0n, Y0t[i] * g0t) + fma_r(Y1n[i], g1n, Y1t[i] * g1t));
+            for (int i = 0; i < NV; ++i) z[i] = fma_r(get(0, i), g0n, get(0, NV + i) * g0t);
+            if (slot > 1) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) z[i] += fma_r(get(1, i), g1n, get(1, NV + i) * g1t);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) z[i] *= invd[i];
             ldl_backward(A, z);
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= z[i];
