@@ -629,14 +629,21 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     EMEI_STAT_WAVE(7);
     R A[NV][NV], invd[NV], a[NV];
     if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
-        build_inertia(A, hd);
-        ldl_factor(A, invd);
+        if (hd > R(0)) {
+            // Euler: solved together with the constrained lanes' damping step at the end (one factorisation of M + h B per
+            // evaluation for the whole wave instead of one per branch: nearly every wave has lanes of both kinds)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) a[i] = f[i];
-        ldl_forward<0, true>(A, a);
+            for (int i = 0; i < NV; ++i) a[i] = R(0);
+        } else {
+            build_inertia(A, R(0));
+            ldl_factor(A, invd);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-        ldl_backward(A, a);
+            for (int i = 0; i < NV; ++i) a[i] = f[i];
+            ldl_forward<0, true>(A, a);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+            ldl_backward(A, a);
+        }
     } else {
         EMEI_MARK(nw_smooth0);
         EMEI_STAT_LANE(1);
@@ -995,24 +1002,26 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
-        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a)
-            R rhs[NV];
+    }
+    if (hd > R(0)) {
+        // mj_EulerSkip for every lane: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a), for the lanes with rows;
+        // free flight (a = 0 above): qacc = (M + h B)^-1 f = 0 - (M + h B)^-1 (-f)
+        R rhs[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) rhs[i] = R(0);
+        for (int i = 0; i < NV; ++i) rhs[i] = rows == 0u ? -f[i] : R(0);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
-                rhs[jc[k]] += t, rhs[jp[k]] -= t;
-            }
-            build_inertia(A, hd);
-            ldl_factor(A, invd);
-            ldl_forward<0, true>(A, rhs);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
-            ldl_backward(A, rhs);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
+        for (int k = 0; k < 6; ++k) {
+            const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
+            rhs[jc[k]] += t, rhs[jp[k]] -= t;
         }
+        build_inertia(A, hd);
+        ldl_factor(A, invd);
+        ldl_forward<0, true>(A, rhs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
+        ldl_backward(A, rhs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
     }
     EMEI_MARK(nw_out);
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[P_TORSO];

@@ -406,14 +406,19 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     EMEI_STAT_LANE(0);
     EMEI_STAT_WAVE(7);
     if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
-        build_inertia(A, hd);
-        ldl_factor(A, invd);
+        if (hd > R(0)) {  // Euler: solved with the constrained lanes' damping step at the end (cheetah_model.h)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) a[i] = f[i];
-        ldl_forward<0>(A, a);
+            for (int i = 0; i < NV; ++i) a[i] = R(0);
+        } else {
+            build_inertia(A, R(0));
+            ldl_factor(A, invd);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-        ldl_backward(A, a);
+            for (int i = 0; i < NV; ++i) a[i] = f[i];
+            ldl_forward<0>(A, a);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+            ldl_backward(A, a);
+        }
     } else {
         EMEI_STAT_LANE(1);
 #ifdef EMEI_NEWTON_STATS
@@ -546,24 +551,24 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
-        if (hd > R(0)) {  // mj_EulerSkip: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a)
-            R rhs[NV];
+    }
+    if (hd > R(0)) {  // mj_EulerSkip for every lane: qacc = a - (M + h B)^-1 (h B a); free flight (a = 0): rhs = -f
+        R rhs[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) rhs[i] = R(0);
+        for (int i = 0; i < NV; ++i) rhs[i] = rows == 0u ? -f[i] : R(0);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
-                rhs[jc[k]] += t, rhs[jp[k]] -= t;
-            }
-            build_inertia(A, hd);
-            ldl_factor(A, invd);
-            ldl_forward<0>(A, rhs);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
-            ldl_backward(A, rhs);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
+        for (int k = 0; k < 3; ++k) {
+            const R t = hd * (R)kGeom.damp[k] * (a[jc[k]] - a[jp[k]]);
+            rhs[jc[k]] += t, rhs[jp[k]] -= t;
         }
+        build_inertia(A, hd);
+        ldl_factor(A, invd);
+        ldl_forward<0>(A, rhs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rhs[i] *= invd[i];
+        ldl_backward(A, rhs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
     }
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[L_TORSO];
     qacc[3] = a[L_TORSO] - a[L_THIGH], qacc[4] = a[L_THIGH] - a[L_LEG], qacc[5] = a[L_LEG] - a[L_FOOT];
