@@ -405,19 +405,19 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     R A[NV][NV], invd[NV], a[NV];
     EMEI_STAT_LANE(0);
     EMEI_STAT_WAVE(7);
+    // qacc_smooth = M^-1 qfrc_smooth for every lane (cheetah_model.h): free flight without implicit damping, the cold start
+    build_inertia(A, R(0));
+    ldl_factor(A, invd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = f[i];
+    ldl_forward<0>(A, a);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+    ldl_backward(A, a);
     if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
         if (hd > R(0)) {  // Euler: solved with the constrained lanes' damping step at the end (cheetah_model.h)
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = R(0);
-        } else {
-            build_inertia(A, R(0));
-            ldl_factor(A, invd);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] = f[i];
-            ldl_forward<0>(A, a);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-            ldl_backward(A, a);
         }
     } else {
         EMEI_STAT_LANE(1);
@@ -429,19 +429,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             EMEI_STAT_WAVE(25);
         }
 #endif
-        // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth
+        // the start of the iteration: the previous minimiser if there is one (RK4 stages), else qacc_smooth
         if (warm.valid) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
-        } else {
-            build_inertia(A, R(0));
-            ldl_factor(A, invd);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] = f[i];
-            ldl_forward<0>(A, a);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-            ldl_backward(A, a);
         }
         R u[NV];
 #pragma unroll
