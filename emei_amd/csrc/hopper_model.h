@@ -422,11 +422,11 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     } else {
         EMEI_STAT_LANE(1);
 #ifdef EMEI_NEWTON_STATS
+        EMEI_STAT_LANE(25 + (__popc(rows) < 6 ? __popc(rows) : 6));  // 26..31: lanes with 1, 2, 3, 4, 5, >= 6 row blocks
         if (__popc(rows) <= 2) {  // how many lanes a two-slot constraint-space path (cheetah_model.h) would serve
             EMEI_STAT_LANE(22);
         } else {
             EMEI_STAT_LANE(24);
-            EMEI_STAT_WAVE(25);
         }
 #endif
         // the start of the iteration: the previous minimiser if there is one (RK4 stages), else qacc_smooth

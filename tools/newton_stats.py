@@ -36,6 +36,9 @@ for env, integ, tu in (("HalfCheetahRunning", "euler", "body_tu_ch_f64"), ("Half
         if dl + pl:
             print(f"   constraint-space path: {dl / (dl + pl):.3f} of the lane evaluations with rows, entered by {dw / ew:.3f} of the wave evaluations; "
                   f"primal loop entered by {pw / ew:.3f}")
+        nb = [int(out[k]) for k in range(26, 32)]
+        if sum(nb):
+            print("   row blocks per lane with rows (permille): " + " ".join(f"{k + 1}{'+' if k == 5 else ''}:{1000 * h / sum(nb):.1f}" for k, h in enumerate(nb)))
         print("   passes per lane evaluation, histogram (permille): " + " ".join(f"{k}:{1000 * h / max(sum(hist), 1):.1f}" for k, h in enumerate(hist) if h))
         print(f"   lanes with rows {s['evals_rows_lane'] / el:.3f}; passes per evaluation: lane {s['passes_lane'] / el:.2f}, wave {s['passes_wave'] / ew:.2f}; "
               f"contact blocks per pass: lane {s['contact_blocks_lane'] / max(s['passes_lane'], 1):.2f}, wave {s['contact_blocks_wave'] / max(s['passes_wave'], 1):.2f}; "
