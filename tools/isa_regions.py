@@ -24,7 +24,7 @@ def flags_for(tag):
     fam = "dp" if body.startswith("dp") else "ip" if body.startswith("ip") else body.rstrip("s") if body in ("chs", "hps") else body
     var = re.sub(r"^(ch|hp|dp|ip)", "", body).replace("s", "") or "0"
     real = "double" if tag.endswith("_f64") else "float"
-    extra = ["-mllvm", "-disable-machine-licm"] if fam in ("ch", "dp") and body not in ("chs",) else []  # as emei_amd/csrc/Makefile: body_flags
+    extra = ["-mllvm", "-disable-machine-licm"] if fam in ("ch", "dp") else []  # as emei_amd/csrc/Makefile: body_flags (ch, chs, dp)
     return extra + [f"-DEMEI_TU_NAME=body_tu_{tag}", f"-DEMEI_BODY_FAM_{body if body in ('chs', 'hps') else fam}", f"-DEMEI_BODY_VARIANT={var}",
             f"-DEMEI_TU_REAL={real}"]
 
