@@ -184,3 +184,30 @@ def test_no_vector_instruction_in_front_of_an_exec_restore(functions):
         if h:
             bad[name] = h[:3]
     assert not bad, bad
+
+
+def test_every_kernel_fits_the_cu(tmp_path):
+    """Resource limits that only show up as a launch failure on the GPU: LDS per block <= 160 KiB (gfx950), the staged
+    pendulum kernels <= 40 KiB (four blocks per CU: DESIGN §4), the Newton cheetah's constraint-space slots inside the
+    budget its kernel states (cheetah_model.h: kDualSlots x kSlotFields values per lane on top of the 32 KiB of staging)."""
+    lib = shutil.copy(LIB, tmp_path)
+    subprocess.check_call([OBJDUMP, "--offloading", lib], stdout=subprocess.DEVNULL, cwd=tmp_path)
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    seen = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        txt = subprocess.check_output([readelf, "--notes", os.path.join(tmp_path, f)], text=True)
+        for blk in txt.split("- .agpr_count:")[1:]:
+            g = dict(re.findall(r"\.(\w+):\s+(\S+)", ".agpr_count:" + blk))
+            if "name" in g:
+                seen[g["name"]] = g
+    assert len(seen) > 100
+    for name, g in seen.items():
+        lds, vg = int(g["group_segment_fixed_size"]), int(g["vgpr_count"])
+        assert lds <= 160 * 1024, (name, lds)
+        assert vg <= 512, (name, vg)
+        if "pend_rollout_staged_kernel" in name:
+            assert lds <= 48 * 1024, (name, lds)  # widest action tiles (int64): 42 KiB; the float32-action InvPend: 38 KiB
+        if "body_rollout_kernel" in name and "CheetahBodyIdLi0" in name:
+            assert lds == 32768 + 2 * 26 * 8 * 256, (name, lds)
