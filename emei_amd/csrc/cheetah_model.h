@@ -647,6 +647,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     } else {
         EMEI_MARK(nw_smooth0);
         EMEI_STAT_LANE(1);
+        EMEI_STAT_LANE(25 + (__popc(rows) < 6 ? __popc(rows) : 6));  // 26..31: lanes with 1, 2, 3, 4, 5, >= 6 row blocks
         // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth (the dual path always
         // needs M's factor and qacc_smooth; a previous minimiser then only provides its first active set)
         const bool dual = kDualSlots > 0 && trig.scratch != nullptr && __popc(rows) <= kDualSlots;
