@@ -289,10 +289,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
         EMEI_LOAD_TILE(t0 + kStage, buf ^ 1)  // next tile: in flight under the 16 steps below
         const ActT* act_l = (const ActT*)&act_s[wv][buf][0];
         ActT act_cur = act_l[lane];
-        // 16 steps = 4 groups (a real loop) x 4 unrolled steps (one reward flush period).  Unrolling all
-        // 16 put ~70 KB of code (each step carries its out-of-line reset and trig-repair blocks) in
-        // the loop, more than the 64 KB instruction cache two CUs share.
-#pragma unroll 1
+        // 16 steps = 4 groups x 4 unrolled steps (one reward flush period), the group loop unrolled by two: at the loop's
+        // back-edge hipcc moves the carried state back into its canonical registers (~18 copies), and with 8 steps per trip
+        // that costs half as much per step — A/B on one box: 0.279 -> 0.270 ms (SwingUp), 0.165 -> 0.160 (Balancing),
+        // 0.613 -> 0.605 (InvertedPendulum).  All 16 unrolled is faster still for Balancing but bimodal for SwingUp
+        // (0.267 / 0.291 ms: the instruction cache two CUs share).
+#ifndef EMEI_GROUP_UNROLL
+#define EMEI_GROUP_UNROLL 2
+#endif
+#pragma unroll EMEI_GROUP_UNROLL
         for (int g = 0; g < kStage / 4; ++g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
