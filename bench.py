@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the fused env-step hot path on N GPUs of one node.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched as
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  One process per GPU: when N > 1 and the process was
+NOT started by a launcher (no WORLD_SIZE in the environment), it starts the N ranks itself — as child processes of
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` —
+without touching the GPU, relays rank 0's ONE JSON line and exits with the launcher's status.  Started under
+`torch.distributed.run` already, it is a rank (RCCL = backend "nccl").  Rank 0 prints ONE JSON line.
 
 A bench "step" = one pass of the hot path over one batch of synthetic input: `emei_rollout` of
 `--horizon` (default 1000 = max_episode_steps of CartPoleSwingUp-v0, register_env.py:19-23) env-steps
@@ -29,7 +31,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-XGMI_PEAK_GBS = 7 * 153.0  # 7 point-to-point xGMI links per GPU x ~153 GB/s: inbound peak of a direct all-gather
+# 7 point-to-point xGMI links per GPU x ~153 GB/s per link (the figure this task states; it is the link's BIDIRECTIONAL rate):
+# what a rank can RECEIVE in a direct all-gather is half of it per link, 7 x 76.8 = 537.6 GB/s
+XGMI_LINKS, XGMI_LINK_GBS_BIDIR = 7, 153.6
+XGMI_PEAK_GBS = XGMI_LINKS * XGMI_LINK_GBS_BIDIR / 2
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md, chip-level parameters)
 MULTI_GPU_SHARD = 131072  # BASELINE configs[4]: 1 048 576 envs / 8 GPUs
 
@@ -55,31 +60,84 @@ def algorithmic_bytes_per_env_step(obs_dim, act_bytes):
     return act_bytes + 4 * obs_dim + 4 + 1
 
 
-def cpu_baseline(env, n, freq_rate, dt, budget_s=12.0):
-    """The CPU oracle ("port": the C restatement of the reference's step arithmetic, pinned
-    bit-exact to the reference by tests/golden) timed on this box's host cores with OpenMP."""
+def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", budget_s=12.0):
+    """The CPU oracle ("port": the C restatement of the reference's step arithmetic — CartPole pinned bit-exact to the
+    reference by tests/golden, the MuJoCo-backed bodies a restatement of MuJoCo's published algorithm) timed on this
+    box's host cores with OpenMP, on the same env kind, env count, freq_rate, dt, integrator and solver as the GPU line."""
     import numpy as np
 
     from oracle import oracle as O
 
-    if not env.startswith("CartPole"):
-        return None
-    variant = "swingup" if env == "CartPoleSwingUp" else "balancing"
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library loads
-    st = O.cartpole_init_state_host(variant, 0, n)
-    acts = np.random.default_rng(1).integers(2, size=(64, n)).astype(np.int32)
-    O.cartpole_step(variant, st, acts[0], freq_rate, dt)  # warm (build + first touch)
+    rng = np.random.default_rng(1)
+    if env.startswith("CartPole"):
+        variant = "swingup" if env == "CartPoleSwingUp" else "balancing"
+        st = O.cartpole_init_state_host(variant, 0, n)
+        acts = rng.integers(2, size=(64, n)).astype(np.int32)
+        step = lambda s, a: O.cartpole_step(variant, s, a, freq_rate, dt)[0]
+    else:
+        opt = O.opts(integrator, solver=solver)
+        if "InvertedDoublePendulum" in env:
+            variant = [k for k in O.DP_VARIANTS if k.replace("_", "") in env.lower().replace("inverteddoublependulum", "")][0]
+            st, acts = rng.standard_normal((n, 6)) * 5e-3, rng.uniform(-1, 1, (64, n))
+            step = lambda s, a: O.dpend_step(variant, s, a, freq_rate, dt, opt)[0]
+        elif "InvertedPendulum" in env:
+            variant = [k for k in O.IP_VARIANTS if k.replace("_", "") in env.lower().replace("invertedpendulum", "")][0]
+            st, acts = rng.standard_normal((n, 4)) * 5e-3, rng.uniform(-3, 3, (64, n))
+            step = lambda s, a: O.ip_step(variant, s, a, freq_rate, dt, opt)[0]
+        elif env == "HalfCheetahRunning":
+            st, acts = rng.standard_normal((n, 18)) * 0.1, rng.uniform(-1, 1, (64, n, 6))
+            step = lambda s, a: O.cheetah_step(s, a, freq_rate, dt, opt)[0]
+        elif env == "HopperRunning":
+            st = rng.standard_normal((n, 12)) * 5e-3
+            st[:, 1] += 1.25
+            acts = rng.uniform(-1, 1, (64, n, 3))
+            step = lambda s, a: O.hopper_step(s, a, freq_rate, dt, opt)[0]
+        else:
+            return None
+    st = step(st, acts[0])  # warm (build + first touch)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        st, _, _ = O.cartpole_step(variant, st, acts[steps % 64], freq_rate, dt)
+        st = step(st, acts[steps % 64])
         steps += 1
         el = time.perf_counter() - t0
         if el > budget_s:
             break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of {n} {env} envs with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+            "sample": f"{steps} steps of {n} {env} envs (freq_rate {freq_rate}, dt {dt}, {integrator}"
+                      + ("" if env.startswith("CartPole") or "Pendulum" in env else f", {solver} solver")
+                      + f") with the C oracle (float64, OpenMP x{cores}, no reset), {el:.1f} s"}
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as children of torch.distributed.run.
+    This process never imports torch and never touches a GPU; it relays rank 0's JSON line and the launcher's status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, EMEI_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes through
+    lines = []
+    for line in p.stdout:
+        if line.startswith("{"):
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = p.wait()
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}\n")
+        rc = 1
+    if rc == 0:
+        print(lines[0], flush=True)
+    raise SystemExit(rc)
 
 
 def main():
@@ -105,6 +163,9 @@ def main():
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)  # does not return
+
     import numpy as np
     import torch
 
@@ -120,6 +181,7 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = "none (1 rank)"
     if world > 1:
         import torch.distributed as dist
 
@@ -245,16 +307,27 @@ def main():
         out["roofline_valu"] = {"bound": "valu_f64", "valu_insts_per_launch": valu, "cycles_per_inst": 4, "simds": SIMDS,
                                 "clock_ghz": CLOCK_GHZ, "frac": valu * 4 / (SIMDS * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3),
                                 "source": f"{prof.get('profile', 'profiles/')} SQ pass via profiles/traffic.json, NOT measured in this run"}
+    # what actually ran: the ranks the process group formed, its backend, every rank's device
+    me = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+    devices = [me]
+    if dist:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+    out["launch"] = {"ranks": dist.get_world_size() if dist else 1, "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+                     "devices": devices, "self_launched": bool(os.environ.get("EMEI_BENCH_SELF_LAUNCHED"))}
     if world > 1:
         gb = sr.gathered_bytes_per_pass
         out["xgmi"] = {"bound": "xgmi", "inbound_bytes_per_rank_per_pass": gb, "achieved": gb * a.steps / el / 1e9,
                        "peak": XGMI_PEAK_GBS, "unit": "GB/s", "frac": gb * a.steps / el / 1e9 / XGMI_PEAK_GBS,
                        "collectives_per_pass": sr.n_chunks if gather != "final" else 1,
-                       "note": "whole-pass average: the all-gathers overlap the rollout launches"}
+                       "peak_source": f"{XGMI_LINKS} links x {XGMI_LINK_GBS_BIDIR} GB/s bidirectional / 2 (inbound)",
+                       "note": "whole-pass average: the all-gathers overlap the rollout launches"
+                               + ("; with --gather per_chunk / per_step every rank receives the whole observation return of its peers, "
+                                  "so N > 1 is bound by xGMI by design, not by the rollout kernel" if gather != "final" else "")}
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(env, N, w["freq_rate"], w["dt"])
+        out["cpu_baseline"] = cpu_baseline(env, N, w["freq_rate"], w["dt"], a.integrator or w.get("integrator", "euler"), a.solver)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

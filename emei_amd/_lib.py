@@ -31,7 +31,9 @@ ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
 FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
-ABI_VERSION = 2
+ABI_VERSION = 3
+IO_F32, IO_F64 = 0, 1  # enum emei_io_dtype
+REWARD_BATCH_CTRL_COST = 1  # flag of emei_reward_io (half_cheetah.py:61 / hopper.py:98: np.sum over the whole batch)
 # enum emei_kernel_id (emei_last_rollout_kernel)
 KERNEL_NAMES = {0: "none", 1: "pend_rollout_staged_kernel<freq1>", 2: "pend_rollout_staged_kernel", 3: "pend_rollout_kernel<full>",
                 4: "pend_rollout_kernel", 5: "body_rollout_kernel", 6: "body_rollout_kernel<rk4>"}
@@ -83,6 +85,7 @@ SYMBOLS = {
     "emei_destroy": (C.c_int, [_vp]),
     "emei_last_error": (C.c_char_p, []),
     "emei_abi_version": (C.c_int, []),
+    "emei_model_constants": (C.c_int, [C.c_int, _vp, C.c_int]),
     "emei_env_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emei_reset": (C.c_int, [_vp, _u64, _vp]),
     "emei_set_seed": (C.c_int, [_vp, _u64]),
@@ -103,6 +106,9 @@ SYMBOLS = {
     "emei_terminal_ex": (C.c_int, [C.c_int, _i64, _vp, _u32, _vp, _vp, _vp]),
     "emei_next_obs": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _vp, _vp]),
     "emei_next_obs_ex": (C.c_int, [C.c_int, _i64, _vp, _vp, C.c_int, _dbl, _i32, _i32, _i32, _vp, _vp]),
+    "emei_reward_io": (C.c_int, [C.c_int, _i64, C.c_int, _vp, _vp, _vp, _dbl, _i32, _u32, _vp, _u32, _vp, _vp]),
+    "emei_terminal_io": (C.c_int, [C.c_int, _i64, C.c_int, _vp, _u32, _vp, _vp, _vp]),
+    "emei_next_obs_io": (C.c_int, [C.c_int, _i64, C.c_int, _vp, _vp, C.c_int, _dbl, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None

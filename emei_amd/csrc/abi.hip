@@ -11,6 +11,9 @@
 
 #include "launch.h"
 #include "body_kernels.h"
+#include "cheetah_model.h"
+#include "hopper_model.h"
+#include "dpend_model.h"
 
 using namespace emei;
 
@@ -72,6 +75,30 @@ extern "C" EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, in
     return EMEI_OK;
 }
 
+extern "C" EMEI_API int emei_model_constants(int env_id, double* out, int capacity) {
+    if (!out || capacity < 0) return fail(EMEI_ERR_INVALID, "emei_model_constants: bad argument");
+    double buf[256];
+    int n;
+    switch (env_id) {
+        case EMEI_IP_REBOUND_BALANCING:
+        case EMEI_IP_BOUNDARY_BALANCING:
+        case EMEI_IP_REBOUND_SWINGUP:
+        case EMEI_IP_BOUNDARY_SWINGUP: n = ip_xml_constants(buf); break;
+        case EMEI_IDP_REBOUND_BALANCING:
+        case EMEI_IDP_BOUNDARY_BALANCING:
+        case EMEI_IDP_REBOUND_SWINGUP:
+        case EMEI_IDP_BOUNDARY_SWINGUP: n = dpend::xml_constants(buf); break;
+        case EMEI_HALFCHEETAH_RUNNING: n = cheetah::xml_constants(buf); break;
+        case EMEI_HOPPER_RUNNING: n = hopper::xml_constants(buf); break;
+        case EMEI_CARTPOLE_SWINGUP:
+        case EMEI_CARTPOLE_BALANCING: return fail(EMEI_ERR_UNSUPPORTED, "emei_model_constants: CartPole has no model file (cartpole.py:22-27)");
+        default: return fail(EMEI_ERR_INVALID, "unknown env_id %d", env_id);
+    }
+    if (n > capacity) return fail(EMEI_ERR_INVALID, "emei_model_constants: %d values, capacity %d", n, capacity);
+    memcpy(out, buf, n * sizeof(double));
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // {sin, cos}(k * 2pi/256), k = 0..255, correctly rounded from long double, one copy per device.
 // Allocated on the first emei_create / stateless call for that device (never inside a hot launch
@@ -122,17 +149,8 @@ static bool steps_as_body(const emei_config& c) {
 static bool is_body(int env_id) { return env_id >= EMEI_HALFCHEETAH_RUNNING && env_id <= EMEI_HOPPER_RUNNING; }
 
 // ---------------------------------------------------------------------------------------------
-// InvertedPendulum model constants from emei/envs/mujoco/assets/inverted_pendulum.xml
-// (gravity :8; slider range :14; cart capsule :15; hinge :17; pole capsule :18; motor :23);
-// capsule mass/inertia are the closed forms MuJoCo's compiler applies for inertiafromgeom.
-static double capsule_mass(double rho, double r, double half) {
-    return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r);
-}
-static double capsule_inertia_perp(double rho, double r, double half) {
-    double h = 2 * half, mcyl = rho * M_PI * r * r * h, msph = rho * 4.0 / 3.0 * M_PI * r * r * r;
-    return mcyl * (3 * r * r + h * h) / 12 + msph * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8);
-}
-
+// Host twin of the InvertedPendulum constants for the launch descriptors: every number comes from pendulum_envs.h:
+// ip_make_model (the one typed copy of emei/envs/mujoco/assets/inverted_pendulum.xml on the kernel side).
 static PendParams pend_params(int env_id, double dt, const float* init_sigma = nullptr, int noise_shared = 0) {
     PendParams p;
     memset(&p, 0, sizeof(p));
@@ -140,26 +158,14 @@ static PendParams pend_params(int env_id, double dt, const float* init_sigma = n
     p.dt32 = (float)dt;
     for (int i = 0; i < 4; ++i) p.init_sigma[i] = init_sigma ? init_sigma[i] : 0.f;
     p.noise_shared = noise_shared;
-    const double rho = 1000.0, g = 9.81;
-    double mc = capsule_mass(rho, 0.1, 0.1);
-    double fx = 0.001, fz = 0.6, len = std::sqrt(fx * fx + fz * fz);
-    double mp = capsule_mass(rho, 0.049, len / 2), Icom = capsule_inertia_perp(rho, 0.049, len / 2), r = len / 2;
-    double phi0 = std::atan2(fx, fz);
-    bool swingup = env_id == EMEI_IP_REBOUND_SWINGUP || env_id == EMEI_IP_BOUNDARY_SWINGUP;
-    p.M11 = mc + mp;
-    p.M22 = Icom + mp * r * r;
-    p.mpr = mp * r;
-    p.mgr = mp * g * r;
-    p.gear = 100.0;
-    p.ctrl_lo = -3.0, p.ctrl_hi = 3.0;
-    p.x_lo = -2.0, p.x_hi = 2.0;
-    p.phi_off = phi0 + (swingup ? M_PI : 0.0);  // _update_model: pole body turned by pi about y
-    p.sin_off = std::sin(p.phi_off);
-    p.cos_off = std::cos(p.phi_off);
-    double c0 = std::cos(phi0), M12 = p.mpr * c0;
-    p.invw = p.M22 / (p.M11 * p.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
-    p.tc = 0.02 < 2 * dt ? 2 * dt : 0.02;          // solref timeconst with MuJoCo's refsafe clamp
-    p.dampratio = 1.0, p.dmin = 0.9, p.dmax = 0.95, p.width = 0.001;
+    const bool swingup = env_id == EMEI_IP_REBOUND_SWINGUP || env_id == EMEI_IP_BOUNDARY_SWINGUP;
+    const IpModel x = ip_make_model(swingup);
+    p.M11 = x.M11, p.M22 = x.M22, p.mpr = x.mpr, p.mgr = x.mp * x.gravity * x.r;
+    p.gear = x.gear, p.ctrl_lo = x.ctrl_lo, p.ctrl_hi = x.ctrl_hi, p.x_lo = x.x_lo, p.x_hi = x.x_hi;
+    p.phi_off = x.phi_off, p.sin_off = x.sin_off, p.cos_off = x.cos_off;  // _update_model: pole body turned by pi about y
+    p.invw = x.invw;                                                      // dof_invweight0 of the slider at qpos0
+    p.tc = x.solref_tc < 2 * dt ? 2 * dt : x.solref_tc;                   // solref timeconst with MuJoCo's refsafe clamp
+    p.dampratio = 1.0, p.dmin = x.dmin, p.dmax = x.dmax, p.width = x.width;
     p.limK = 1.0 / (p.dmax * p.dmax * p.tc * p.tc * p.dampratio * p.dampratio), p.limB = 2.0 / (p.dmax * p.tc);
     return p;
 }
@@ -446,7 +452,7 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
     } else {
         BodyLaunch L = body_base(h, stream);
         L.op = BODY_OP_ROLLOUT;
-        L.actions = (const float*)actions;
+        L.actions = actions;
         L.obs_out = obs_out;
         L.reward_out = reward_out;
         L.done_out = done_out;
@@ -517,17 +523,26 @@ static int fill_env_params(int env_id, uint32_t mask, const double* params, EnvP
     return EMEI_OK;
 }
 
-extern "C" EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+static bool bad_io(int io_dtype) { return io_dtype != EMEI_IO_F32 && io_dtype != EMEI_IO_F64; }
+static bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
+
+extern "C" EMEI_API int emei_reward_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* pre_obs, const void* action,
                               double real_time_scale, int32_t freq_rate, uint32_t env_param_mask, const double* env_params,
-                              float* reward_out, void* stream) {
+                              uint32_t flags, void* reward_out, void* stream) {
     if (n <= 0 || !obs || !reward_out) return fail(EMEI_ERR_INVALID, "emei_reward: bad argument");
+    if (bad_io(io_dtype)) return fail(EMEI_ERR_INVALID, "emei_reward: io_dtype=%d", io_dtype);
+    if (flags & ~EMEI_REWARD_BATCH_CTRL_COST) return fail(EMEI_ERR_INVALID, "emei_reward: unknown flags 0x%x", flags);
+    if ((flags & EMEI_REWARD_BATCH_CTRL_COST) && env_id != EMEI_HALFCHEETAH_RUNNING && env_id != EMEI_HOPPER_RUNNING)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_reward: env_id %d has no control-cost term to sum over the batch", env_id);
     if (is_pend(env_id)) {
+        if (misaligned16(obs)) return fail(EMEI_ERR_INVALID, "emei_reward: obs must be 16-byte aligned");
         PendLaunch L;
         L.op = PEND_OP_REWARD_TERMINAL;
         L.env_id = env_id;
-        L.precision = EMEI_PRECISION_REF;  // float32 in/out, evaluated in float64
+        L.precision = EMEI_PRECISION_REF;  // evaluated in float64 whatever the row dtype
         L.obs_in = obs;
-        L.reward_out = reward_out;
+        L.io_f64 = io_dtype == EMEI_IO_F64;
+        L.reward_out = (float*)reward_out;
         L.n = n;
         L.p = pend_params(env_id, real_time_scale > 0 ? real_time_scale : 0.02);
         L.trig = current_device_trig();
@@ -545,31 +560,45 @@ extern "C" EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, 
         L.env_id = env_id;
         L.precision = EMEI_PRECISION_REF;
         L.obs_in = obs, L.pre_obs_in = pre_obs, L.actions = action;
-        L.reward_out = reward_out;
+        L.io_f64 = io_dtype == EMEI_IO_F64;
+        L.reward_out = (float*)reward_out;
         L.n = n;
         L.freq_rate = freq_rate;
         L.dt = real_time_scale;
         L.stream = (hipStream_t)stream;
+        if (flags & EMEI_REWARD_BATCH_CTRL_COST)  // 8 B for the whole-batch sum, allocated and freed in stream order
+            HIP_TRY(hipMallocAsync((void**)&L.batch_cost_scratch, sizeof(double), L.stream));
         int rc = body_launch(L);
+        if (L.batch_cost_scratch) (void)hipFreeAsync(L.batch_cost_scratch, L.stream);
         return rc == EMEI_OK ? rc : fail(rc, "emei_reward: launch failed");
     }
     return fail(EMEI_ERR_INVALID, "emei_reward: unknown env_id %d", env_id);
 }
 
-extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
-                           double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {
-    return emei_reward_ex(env_id, n, obs, pre_obs, action, real_time_scale, freq_rate, 0u, nullptr, reward_out, stream);
+extern "C" EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                              double real_time_scale, int32_t freq_rate, uint32_t env_param_mask, const double* env_params,
+                              float* reward_out, void* stream) {
+    return emei_reward_io(env_id, n, EMEI_IO_F32, obs, pre_obs, action, real_time_scale, freq_rate, env_param_mask, env_params, 0u,
+                          reward_out, stream);
 }
 
-extern "C" EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t env_param_mask,
+extern "C" EMEI_API int emei_reward(int env_id, int64_t n, const float* obs, const float* pre_obs, const float* action,
+                           double real_time_scale, int32_t freq_rate, float* reward_out, void* stream) {
+    return emei_reward_io(env_id, n, EMEI_IO_F32, obs, pre_obs, action, real_time_scale, freq_rate, 0u, nullptr, 0u, reward_out, stream);
+}
+
+extern "C" EMEI_API int emei_terminal_io(int env_id, int64_t n, int io_dtype, const void* obs, uint32_t env_param_mask,
                                 const double* env_params, uint8_t* terminal_out, void* stream) {
     if (n <= 0 || !obs || !terminal_out) return fail(EMEI_ERR_INVALID, "emei_terminal: bad argument");
+    if (bad_io(io_dtype)) return fail(EMEI_ERR_INVALID, "emei_terminal: io_dtype=%d", io_dtype);
     if (is_pend(env_id)) {
+        if (misaligned16(obs)) return fail(EMEI_ERR_INVALID, "emei_terminal: obs must be 16-byte aligned");
         PendLaunch L;
         L.op = PEND_OP_REWARD_TERMINAL;
         L.env_id = env_id;
         L.precision = EMEI_PRECISION_REF;
         L.obs_in = obs;
+        L.io_f64 = io_dtype == EMEI_IO_F64;
         L.done_out = terminal_out;
         L.n = n;
         L.p = pend_params(env_id, 0.02);
@@ -585,6 +614,7 @@ extern "C" EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs
         L.env_id = env_id;
         L.precision = EMEI_PRECISION_REF;
         L.obs_in = obs;
+        L.io_f64 = io_dtype == EMEI_IO_F64;
         L.done_out = terminal_out;
         L.n = n;
         L.stream = (hipStream_t)stream;
@@ -594,30 +624,39 @@ extern "C" EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs
     return fail(EMEI_ERR_INVALID, "emei_terminal: unknown env_id %d", env_id);
 }
 
-extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream) {
-    return emei_terminal_ex(env_id, n, obs, 0u, nullptr, terminal_out, stream);
+extern "C" EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t env_param_mask,
+                                const double* env_params, uint8_t* terminal_out, void* stream) {
+    return emei_terminal_io(env_id, n, EMEI_IO_F32, obs, env_param_mask, env_params, terminal_out, stream);
 }
 
-extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+extern "C" EMEI_API int emei_terminal(int env_id, int64_t n, const float* obs, uint8_t* terminal_out, void* stream) {
+    return emei_terminal_io(env_id, n, EMEI_IO_F32, obs, 0u, nullptr, terminal_out, stream);
+}
+
+extern "C" EMEI_API int emei_next_obs_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* actions, int action_dtype,
                                 double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
-                                float* next_obs_out, void* stream) {
+                                void* next_obs_out, void* stream) {
     if (n <= 0 || !obs || !actions || !next_obs_out) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad argument");
+    if (bad_io(io_dtype)) return fail(EMEI_ERR_INVALID, "emei_next_obs: io_dtype=%d", io_dtype);
     if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad dt/freq_rate");
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype");
+    if (precision != EMEI_PRECISION_REF && precision != EMEI_PRECISION_F32) return fail(EMEI_ERR_INVALID, "emei_next_obs: precision=%d", precision);
     if (integrator < EMEI_INTEG_EULER || integrator > EMEI_INTEG_RK4)
         return fail(EMEI_ERR_UNSUPPORTED, "emei_next_obs: integrator=%d", integrator);
     int od, ad, sd;
     if (emei_env_dims(env_id, &od, &ad, &sd) != EMEI_OK) return EMEI_ERR_INVALID;
     const bool ip_as_body = is_ip(env_id) && integrator != EMEI_INTEG_EULER;
     if (is_pend(env_id) && !ip_as_body) {
+        if (misaligned16(obs) || misaligned16(next_obs_out)) return fail(EMEI_ERR_INVALID, "emei_next_obs: obs / next_obs_out must be 16-byte aligned");
         PendLaunch L;
         L.op = PEND_OP_NEXT_OBS;
         L.env_id = env_id;
         L.precision = precision;
         L.obs_in = obs;
+        L.io_f64 = io_dtype == EMEI_IO_F64;
         L.actions = actions;
         L.action_dtype = action_dtype;
-        L.obs_out = next_obs_out;
+        L.obs_out = (float*)next_obs_out;
         L.n = n;
         L.freq_rate = freq_rate;
         L.p = pend_params(env_id, real_time_scale);
@@ -632,8 +671,9 @@ extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs
     L.env_id = env_id;
     L.precision = precision;
     L.obs_in = obs;
-    L.actions = (const float*)actions;
-    L.obs_out = next_obs_out;
+    L.io_f64 = io_dtype == EMEI_IO_F64;
+    L.actions = actions;
+    L.obs_out = (float*)next_obs_out;
     L.n = n;
     L.freq_rate = freq_rate;
     L.dt = real_time_scale;
@@ -646,9 +686,16 @@ extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs
     return rc == EMEI_OK ? rc : fail(rc, "emei_next_obs: launch failed");
 }
 
+extern "C" EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
+                                double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
+                                float* next_obs_out, void* stream) {
+    return emei_next_obs_io(env_id, n, EMEI_IO_F32, obs, actions, action_dtype, real_time_scale, freq_rate, precision, integrator,
+                            next_obs_out, stream);
+}
+
 extern "C" EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
                              double real_time_scale, int32_t freq_rate, int32_t precision, float* next_obs_out,
                              void* stream) {
-    return emei_next_obs_ex(env_id, n, obs, actions, action_dtype, real_time_scale, freq_rate, precision, EMEI_INTEG_EULER,
+    return emei_next_obs_io(env_id, n, EMEI_IO_F32, obs, actions, action_dtype, real_time_scale, freq_rate, precision, EMEI_INTEG_EULER,
                             next_obs_out, stream);
 }

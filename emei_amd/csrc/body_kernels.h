@@ -13,7 +13,8 @@
 //   outputs(s, pre, ctrl, m, freq_rate, obs, rew, terminal, trig)   // obs / reward / terminal of a finished step
 //   init_base(s)                                    // non-zero entries of init_qpos (added after the init noise)
 //   obs_of(s, o)                                    // observation of a state (float64, for emei_get_obs)
-//   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 rows
+//   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 or float64 rows
+//   kHasCtrlCost, ctrl_cost(act)                    // the reward has a control-cost term w_ctrl * sum a^2 (whole-batch quirk mode)
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
 //   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
@@ -164,9 +165,11 @@ struct BodyLaunch {
     int32_t* steps = nullptr;
     uint32_t* episode = nullptr;
     unsigned long long* done_mask = nullptr;
-    const float* actions = nullptr;
-    const float* obs_in = nullptr;
-    const float* pre_obs_in = nullptr;
+    const void* actions = nullptr;     // rollout / next_obs: float32 [.., n, NA]; BODY_OP_REWARD: dtype of obs_in
+    const void* obs_in = nullptr;      // stateless ops: [n, NO] float32, or float64 when io_f64
+    const void* pre_obs_in = nullptr;
+    int io_f64 = 0;                    // stateless ops: obs_in / pre_obs_in / obs_out / reward_out (and the reward's actions) are float64
+    double* batch_cost_scratch = nullptr;  // BODY_OP_REWARD with EMEI_REWARD_BATCH_CTRL_COST: 8 B of device scratch
     const int64_t* env_index = nullptr;
     const uint32_t* episode_in = nullptr;
     float* obs_out = nullptr;
@@ -415,29 +418,50 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < Body::NO; ++j) obs[k * Body::NO + j] = (float)o[j];
 }
 
-// get_batch_reward / get_batch_terminal on float32 rows
-template <class Body>
+// get_batch_reward / get_batch_terminal on rows of the caller's dtype T (float or double; float64 rows are not narrowed:
+// the reference evaluates these on float64 arrays, half_cheetah.py:59-67, hopper.py:95-106)
+template <class Body, typename T>
 __global__ void __launch_bounds__(kBlock)
-    body_reward_kernel(const float* obs, const float* pre_obs, const float* action, float* reward, int64_t n,
-                       int freq_rate, typename Body::Model m) {
+    body_reward_kernel(const T* obs, const T* pre_obs, const T* action, T* reward, int64_t n, int freq_rate,
+                       typename Body::Model m, const double* batch_cost) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    reward[i] = (float)Body::batch_reward(obs + i * Body::NO, pre_obs ? pre_obs + i * Body::NO : nullptr,
-                                          action ? action + i * Body::NA : nullptr, m, freq_rate);
+    double r = Body::batch_reward(obs + i * Body::NO, pre_obs ? pre_obs + i * Body::NO : nullptr,
+                                  action ? action + i * Body::NA : nullptr, m, freq_rate);
+    if constexpr (Body::kHasCtrlCost) {
+        // EMEI_REWARD_BATCH_CTRL_COST (half_cheetah.py:61): replace this row's control cost by the whole batch's
+        if (batch_cost) r += m.w_ctrl * (Body::ctrl_cost(action + i * Body::NA) - *batch_cost);
+    }
+    reward[i] = (T)r;
 }
-template <class Body>
+// sum over the WHOLE batch of action^2 in one workgroup, in a fixed order (deterministic): np.sum(np.square(action)) of
+// half_cheetah.py:61
+template <typename T>
+__global__ void __launch_bounds__(1024) batch_sumsq_kernel(const T* x, int64_t count, double* out) {
+    __shared__ double part[1024];
+    double acc = 0.0;
+    for (int64_t k = threadIdx.x; k < count; k += 1024) acc += (double)x[k] * (double)x[k];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
+}
+template <class Body, typename T>
 __global__ void __launch_bounds__(kBlock)
-    body_terminal_kernel(const float* obs, uint8_t* terminal, int64_t n, typename Body::Model m) {
+    body_terminal_kernel(const T* obs, uint8_t* terminal, int64_t n, typename Body::Model m) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     terminal[i] = (uint8_t)Body::batch_terminal(obs + i * Body::NO, m);
 }
 
 // EmeiEnv.get_batch_next_obs (core.py:190-193; abstract in the reference): one env-step from caller-supplied
-// float32 observations, for bodies whose observation determines the state (Body::kObsIsState)
-template <class Body, bool RK4>
+// observations of dtype T, for bodies whose observation determines the state (Body::kObsIsState)
+template <class Body, bool RK4, typename T>
 __global__ void __launch_bounds__(kBlock)
-    body_next_obs_kernel(const float* obs, const float* actions, float* next_obs, int64_t n, int freq_rate, int semi,
+    body_next_obs_kernel(const T* obs, const float* actions, T* next_obs, int64_t n, int freq_rate, int semi,
                          typename Body::Model m, const SinCosEntry* trig_tab) {
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
@@ -457,11 +481,18 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < NA; ++k) ctrl[k] = (R)actions[i * NA + k];
     typename Body::Warm warm{};
     for (int k = 0; k < freq_rate; ++k) body_substep<Body, RK4>(s, ctrl, m, semi != 0, trig, warm);
-    float o[NO];
-    bool term;
-    Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term, trig);
+    if constexpr (sizeof(T) == 8) {  // float64 rows: the observation of the float64 state, unrounded
+        double o[NO];
+        Body::obs_of(s, o, m);
 #pragma unroll
-    for (int k = 0; k < NO; ++k) next_obs[i * NO + k] = o[k];
+        for (int k = 0; k < NO; ++k) next_obs[i * NO + k] = o[k];
+    } else {
+        float o[NO];
+        bool term;
+        Body::outputs(s, pre, ctrl, m, freq_rate, o, rew, term, trig);
+#pragma unroll
+        for (int k = 0; k < NO; ++k) next_obs[i * NO + k] = o[k];
+    }
 }
 
 // every launch of one Body type (one translation unit instantiates exactly one Body: body_tu.hip)
@@ -474,7 +505,7 @@ static int launch_body(const BodyLaunch& L) {
         case BODY_OP_ROLLOUT: {
             BodyArgs<Body> a;
             a.state = (R*)L.state, a.steps = L.steps, a.episode = L.episode, a.done_mask = L.done_mask;
-            a.actions = L.actions, a.obs_out = L.obs_out, a.reward_out = L.reward_out, a.done_out = L.done_out;
+            a.actions = (const float*)L.actions, a.obs_out = L.obs_out, a.reward_out = L.reward_out, a.done_out = L.done_out;
             a.n = L.n, a.n_steps = L.n_steps, a.freq_rate = L.freq_rate, a.max_episode_steps = L.max_episode_steps;
             a.flags = L.flags, a.seed = L.seed, a.env_offset = L.env_offset, a.m = m;
             a.semi = L.integrator == EMEI_INTEG_SEMI_IMPLICIT, a.noise = NoiseArgs<Body::NS>(L.noise);
@@ -498,22 +529,54 @@ static int launch_body(const BodyLaunch& L) {
             hipLaunchKernelGGL(body_init_obs_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.env_index, L.episode_in,
                                L.obs_out, L.n, L.seed, L.env_offset, NoiseArgs<Body::NS>(L.noise), m);
             break;
-        case BODY_OP_REWARD:
-            hipLaunchKernelGGL(body_reward_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.pre_obs_in,
-                               L.actions, L.reward_out, L.n, L.freq_rate, m);
+        case BODY_OP_REWARD: {
+            const double* bc = nullptr;
+            if (L.batch_cost_scratch) {  // EMEI_REWARD_BATCH_CTRL_COST: whole-batch sum of action^2 first (stream-ordered)
+                if constexpr (!Body::kHasCtrlCost) return EMEI_ERR_UNSUPPORTED;
+                bc = L.batch_cost_scratch;
+                if (L.io_f64)
+                    hipLaunchKernelGGL(batch_sumsq_kernel<double>, dim3(1), dim3(1024), 0, L.stream, (const double*)L.actions,
+                                       L.n * Body::NA, L.batch_cost_scratch);
+                else
+                    hipLaunchKernelGGL(batch_sumsq_kernel<float>, dim3(1), dim3(1024), 0, L.stream, (const float*)L.actions,
+                                       L.n * Body::NA, L.batch_cost_scratch);
+            }
+            if (L.io_f64)
+                hipLaunchKernelGGL((body_reward_kernel<Body, double>), grid, dim3(kBlock), 0, L.stream, (const double*)L.obs_in,
+                                   (const double*)L.pre_obs_in, (const double*)L.actions, (double*)L.reward_out, L.n, L.freq_rate, m, bc);
+            else
+                hipLaunchKernelGGL((body_reward_kernel<Body, float>), grid, dim3(kBlock), 0, L.stream, (const float*)L.obs_in,
+                                   (const float*)L.pre_obs_in, (const float*)L.actions, (float*)L.reward_out, L.n, L.freq_rate, m, bc);
             break;
+        }
         case BODY_OP_TERMINAL:
-            hipLaunchKernelGGL(body_terminal_kernel<Body>, grid, dim3(kBlock), 0, L.stream, L.obs_in, L.done_out, L.n, m);
+            if (L.io_f64)
+                hipLaunchKernelGGL((body_terminal_kernel<Body, double>), grid, dim3(kBlock), 0, L.stream, (const double*)L.obs_in,
+                                   L.done_out, L.n, m);
+            else
+                hipLaunchKernelGGL((body_terminal_kernel<Body, float>), grid, dim3(kBlock), 0, L.stream, (const float*)L.obs_in,
+                                   L.done_out, L.n, m);
             break;
         case BODY_OP_NEXT_OBS:
             if constexpr (Body::kObsIsState) {
-                if (L.integrator == EMEI_INTEG_RK4)
-                    hipLaunchKernelGGL((body_next_obs_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
-                                       L.obs_out, L.n, L.freq_rate, 0, m, (const SinCosEntry*)L.trig);
-                else
-                    hipLaunchKernelGGL((body_next_obs_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, L.obs_in, L.actions,
-                                       L.obs_out, L.n, L.freq_rate, (int)(L.integrator == EMEI_INTEG_SEMI_IMPLICIT), m,
-                                       (const SinCosEntry*)L.trig);
+                const int semi = (int)(L.integrator == EMEI_INTEG_SEMI_IMPLICIT);
+                const SinCosEntry* tt = (const SinCosEntry*)L.trig;
+                const float* act = (const float*)L.actions;
+                if (L.integrator == EMEI_INTEG_RK4) {
+                    if (L.io_f64)
+                        hipLaunchKernelGGL((body_next_obs_kernel<Body, true, double>), grid, dim3(kBlock), 0, L.stream,
+                                           (const double*)L.obs_in, act, (double*)L.obs_out, L.n, L.freq_rate, 0, m, tt);
+                    else
+                        hipLaunchKernelGGL((body_next_obs_kernel<Body, true, float>), grid, dim3(kBlock), 0, L.stream,
+                                           (const float*)L.obs_in, act, (float*)L.obs_out, L.n, L.freq_rate, 0, m, tt);
+                } else {
+                    if (L.io_f64)
+                        hipLaunchKernelGGL((body_next_obs_kernel<Body, false, double>), grid, dim3(kBlock), 0, L.stream,
+                                           (const double*)L.obs_in, act, (double*)L.obs_out, L.n, L.freq_rate, semi, m, tt);
+                    else
+                        hipLaunchKernelGGL((body_next_obs_kernel<Body, false, float>), grid, dim3(kBlock), 0, L.stream,
+                                           (const float*)L.obs_in, act, (float*)L.obs_out, L.n, L.freq_rate, semi, m, tt);
+                }
                 break;
             } else {
                 return EMEI_ERR_UNSUPPORTED;  // e.g. the double pendulum's observation "wrap" is not invertible

@@ -101,25 +101,36 @@ constexpr double capsule_inertia_perp(double rho, double r, double half) {
 }
 }  // namespace cheetah_host
 
-constexpr Model cheetah_make_model(double dt) {
+// the XML-level tables (hand-typed from half_cheetah.xml:62-95; pinned to the file by tests/test_model_constants.py through
+// emei_model_constants) and what MuJoCo's compiler derives from them: mass, centre of mass and inertia of every body
+constexpr double kCtrlLo = -1.0, kCtrlHi = 1.0;  // <motor ctrllimited ctrlrange="-1 1"> (xml:40)
+constexpr double kSolrefTc = 0.02;               // solref / solreflimit ".02 1" (xml:37-38): time constant, damping ratio 1
+struct CheetahGeom {
+    int body;
+    cheetah_host::H2 c;
+    double ang, half;
+};
+struct CheetahBodies {
+    int parent[7];
+    cheetah_host::H2 bpos[7];  // body origin = joint anchor, parent frame (torso: world)
+    CheetahGeom g[8];          // capsules torso, head, bthigh, bshin, bfoot, fthigh, fshin, ffoot: body, centre, angle about y, half-length
+    double r, total_mass;
+    double mass[7], inertia[7];  // after settotalmass
+    cheetah_host::H2 com[7];
+};
+constexpr CheetahBodies cheetah_bodies() {
     using namespace cheetah_host;
-    Model m{};
     const double r = 0.046, rho = 1000.0;
     // bodies in the xml's order: torso, bthigh, bshin, bfoot, fthigh, fshin, ffoot
-    const int parent[7] = {-1, 0, 1, 2, 0, 4, 5};
-    const H2 bpos[7] = {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}};
-    struct G {
-        int body;
-        H2 c;
-        double ang, half;
-    };
-    const G g[8] = {{0, {0, 0}, M_PI / 2, 0.5},       {0, {0.6, 0.1}, 0.87, 0.15},       {1, {0.1, -0.13}, -3.8, 0.145},
-              {2, {-0.14, -0.07}, -2.03, 0.15}, {3, {0.03, -0.097}, -0.27, 0.094}, {4, {-0.07, -0.12}, 0.52, 0.133},
-              {5, {0.065, -0.09}, -0.6, 0.106}, {6, {0.045, -0.07}, -0.6, 0.07}};
+    CheetahBodies B{{-1, 0, 1, 2, 0, 4, 5},
+                    {{0, 0.7}, {-0.5, 0}, {0.16, -0.25}, {-0.28, -0.14}, {0.5, 0}, {-0.14, -0.24}, {0.13, -0.18}},
+                    {{0, {0, 0}, M_PI / 2, 0.5},       {0, {0.6, 0.1}, 0.87, 0.15},       {1, {0.1, -0.13}, -3.8, 0.145},
+                     {2, {-0.14, -0.07}, -2.03, 0.15}, {3, {0.03, -0.097}, -0.27, 0.094}, {4, {-0.07, -0.12}, 0.52, 0.133},
+                     {5, {0.065, -0.09}, -0.6, 0.106}, {6, {0.045, -0.07}, -0.6, 0.07}},
+                    r, 14.0, {}, {}, {}};
+    const CheetahGeom(&g)[8] = B.g;
     double gm[8] = {}, gi[8] = {}, total = 0;
     for (int k = 0; k < 8; ++k) gm[k] = capsule_mass(rho, r, g[k].half), gi[k] = capsule_inertia_perp(rho, r, g[k].half), total += gm[k];
-    double mass[7] = {}, inertia[7] = {};
-    H2 com[7] = {};
     for (int b = 0; b < 7; ++b) {
         double mb = 0;
         H2 c = {0, 0};
@@ -132,10 +143,24 @@ constexpr Model cheetah_make_model(double dt) {
                 double dx = g[k].c.x - c.x, dz = g[k].c.z - c.z;
                 I += gi[k] + gm[k] * (dx * dx + dz * dz);
             }
-        mass[b] = mb, com[b] = c, inertia[b] = I;
+        B.mass[b] = mb, B.com[b] = c, B.inertia[b] = I;
     }
-    const double s = 14.0 / total;
-    for (int b = 0; b < 7; ++b) mass[b] *= s, inertia[b] *= s;
+    const double s = B.total_mass / total;  // settotalmass (xml:35): masses and inertias scale together
+    for (int b = 0; b < 7; ++b) B.mass[b] *= s, B.inertia[b] *= s;
+    return B;
+}
+
+constexpr Model cheetah_make_model(double dt) {
+    using namespace cheetah_host;
+    Model m{};
+    const CheetahBodies B = cheetah_bodies();
+    const double r = B.r;
+    const int(&parent)[7] = B.parent;
+    const H2(&bpos)[7] = B.bpos;
+    const CheetahGeom(&g)[8] = B.g;
+    const double(&mass)[7] = B.mass;
+    const double(&inertia)[7] = B.inertia;
+    const H2(&com)[7] = B.com;
     // subtree masses
     double sub[7] = {};
     for (int b = 0; b < 7; ++b) sub[b] = mass[b];
@@ -172,7 +197,7 @@ constexpr Model cheetah_make_model(double dt) {
     }
     m.radius = r, m.friction = 0.4;
     // solref (.02, 1) with MuJoCo's refsafe clamp timeconst >= 2 dt; solimp contacts (0,.8,.01), limits (0,.8,.03)
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.8;
+    const double tc = kSolrefTc < 2 * dt ? 2 * dt : kSolrefTc, dmax = 0.8;
     m.cK = m.lK = 1.0 / (dmax * dmax * tc * tc), m.cB = m.lB = 2.0 / (dmax * tc);
     m.c_dmin = 0.0, m.c_dmax = dmax, m.c_width = 0.01;
     m.l_dmin = 0.0, m.l_dmax = dmax, m.l_width = 0.03;
@@ -182,6 +207,33 @@ constexpr Model cheetah_make_model(double dt) {
 
 // every dt-independent constant of the model, as compile-time immediates for the device code
 __device__ constexpr Model kGeom = cheetah_make_model(0.002);
+
+// emei_model_constants (include/emei_hip.h): the tables above in the layout documented there, for the test that pins them
+// to the reference's XML.  Host only; reads the SAME constexpr objects the kernels are compiled from.
+inline int xml_constants(double* out) {
+    constexpr CheetahBodies B = cheetah_bodies();
+    constexpr Model m = cheetah_make_model(0.002);
+    int n = 0;
+    out[n++] = m.gravity;
+    for (int b = 0; b < 7; ++b) {
+        const double row[6] = {B.mass[b], B.com[b].x, B.com[b].z, B.inertia[b], B.bpos[b].x, B.bpos[b].z};
+        for (double v : row) out[n++] = v;
+    }
+    for (int k = 0; k < 8; ++k) {
+        const double row[7] = {(double)B.g[k].body, m.geom_end[2 * k][0], m.geom_end[2 * k][1], m.geom_end[2 * k + 1][0],
+                               m.geom_end[2 * k + 1][1], m.radius, m.friction};
+        for (double v : row) out[n++] = v;
+    }
+    for (int k = 0; k < 6; ++k) {
+        const double row[6] = {m.stiff[k], m.damp[k], m.arm[k], m.lo[k], m.hi[k], m.gear[k]};
+        for (double v : row) out[n++] = v;
+    }
+    const double tail[13] = {0.0 /* contact margin */, kSolrefTc,
+                             m.c_dmin, m.c_dmax, m.c_width, kSolrefTc, m.l_dmin, m.l_dmax, m.l_width, kCtrlLo, kCtrlHi,
+                             0.0 /* rootz ref */, 1.0 /* hinges about +y */};
+    for (double v : tail) out[n++] = v;
+    return n;
+}
 
 // Inverse weights at qpos0 (MuJoCo's mj_setConst; the diagonal approximation of J M^-1 J' that scales the constraint
 // regularisers): (M0^-1)_jj of the six leg joints (bthigh .. ffoot) and the mean translational inverse inertia
@@ -337,7 +389,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     constexpr int jp[6] = {P_TORSO, P_BTHIGH, P_BSHIN, P_TORSO, P_FTHIGH, P_FSHIN};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);   // ctrlrange +-1
+        const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);   // ctrlrange +-1
         const R tau = (R)kGeom.gear[k] * c - (R)kGeom.stiff[k] * q[3 + k] - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] += tau;
         f[jp[k]] -= tau;
@@ -598,7 +650,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                            w2[3] * dotperp(S[3], Dtf) + w2[4] * dotperp(S[4], Dtf) + w2[5] * dotperp(S[5], Dtf));
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);
+        const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);
         const R tau = (R)kGeom.gear[k] * c - (R)kGeom.stiff[k] * q[3 + k] - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] += tau;
         f[jp[k]] -= tau;
@@ -1045,6 +1097,7 @@ struct CheetahBody {
 #endif
     static constexpr bool kUnrollRK4 = EMEI_CHEETAH_UNROLL_RK4 != 0;
     static constexpr int kScratchPerLane = SOLVER == EMEI_SOLVER_NEWTON ? cheetah::kDualSlots * cheetah::kSlotFields : 0;
+    static constexpr bool kHasCtrlCost = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 18, NO = 18, NA = 6;
@@ -1081,14 +1134,23 @@ struct CheetahBody {
     }
     // half_cheetah.py:59-63 for one row (the reference's batch form sums np.square(action) over the WHOLE
     // batch, a quirk documented in DESIGN.md); float32 in, float64 arithmetic
-    __device__ __forceinline__ static double batch_reward(const float* obs, const float* pre_obs, const float* act,
+    template <typename T>
+    __device__ __forceinline__ static double ctrl_cost(const T* act) {  // this row's sum a^2, float64 (half_cheetah.py:61)
+        double cost = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
+        return cost;
+    }
+    template <typename T>
+    __device__ __forceinline__ static double batch_reward(const T* obs, const T* pre_obs, const T* act,
                                                           const Model& m, int freq_rate) {
         double cost = 0.0;
 #pragma unroll
         for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
         return m.w_forward * ((double)obs[0] - (double)pre_obs[0]) / (m.dt * freq_rate) - m.w_ctrl * cost;
     }
-    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model&) {
+    template <typename T>
+    __device__ __forceinline__ static bool batch_terminal(const T* obs, const Model&) {
         bool fin = true;
 #pragma unroll
         for (int k = 0; k < NO; ++k) fin &= finite_r(obs[k]);

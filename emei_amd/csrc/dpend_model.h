@@ -33,30 +33,53 @@ inline double capsule_inertia_perp(double rho, double r, double half) {
 }
 }  // namespace host
 
+// the XML-level numbers (hand-typed from inverted_double_pendulum.xml; pinned to the file by tests/test_model_constants.py
+// through emei_model_constants)
+struct Xml {
+    double rho, cart_r, cart_half, pole_r, pole_half, L1, gx, gz, gear, ctrl_lo, ctrl_hi, x_lo, x_hi, margin, solref_tc, dmin, dmax, width;
+};
+constexpr Xml kXml = {1000.0, 0.1, 0.1,      // density (MuJoCo default); cart capsule size="0.1 0.1" (xml:32)
+                      0.045, 0.3, 0.6,       // each pole: fromto 0 0 0 0 0 0.6, r .045 (xml:35,38); pole 2 hangs at z = .6 (xml:36)
+                      1e-5, 9.81,            // gravity "1e-5 0 -9.81" (xml:26)
+                      500.0, -1.0, 1.0,      // motor gear, ctrlrange (xml:45)
+                      -3.0, 3.0, 0.01,       // slider range, margin (xml:31)
+                      0.02, 0.9, 0.95, 0.001};  // default solref (.02 1), solimp (.9 .95 .001)
+
 inline Model make_model(bool swingup, double dt) {
     Model m;
     memset(&m, 0, sizeof(m));
-    const double rho = 1000.0;
-    const double mc = host::capsule_mass(rho, 0.1, 0.1);                      // cart capsule, xml:32
-    const double mp = host::capsule_mass(rho, 0.045, 0.3);                    // each pole: fromto 0..0.6, r .045 (xml:35,38)
-    const double Ip = host::capsule_inertia_perp(rho, 0.045, 0.3);
-    const double lc = 0.3, L1 = 0.6;                                          // pole com, pole-2 attachment (xml:36)
+    const double rho = kXml.rho;
+    const double mc = host::capsule_mass(rho, kXml.cart_r, kXml.cart_half);
+    const double mp = host::capsule_mass(rho, kXml.pole_r, kXml.pole_half);
+    const double Ip = host::capsule_inertia_perp(rho, kXml.pole_r, kXml.pole_half);
+    const double lc = kXml.pole_half, L1 = kXml.L1;                           // pole com, pole-2 attachment
     m.s1z = mp * lc + mp * L1, m.s2z = mp * lc;
     m.diag1 = Ip + mp * lc * lc + mp * L1 * L1, m.diag2 = Ip + mp * lc * lc;
     m.L1 = L1, m.mtot = mc + 2 * mp;
-    m.gx = 1e-5, m.gz = 9.81;                                                 // gravity "1e-5 0 -9.81" (xml:26)
-    m.gear = 500.0;                                                           // xml:45, ctrlrange +-1
-    m.x_lo = -3.0, m.x_hi = 3.0, m.margin = 0.01;                             // xml:31
+    m.gx = kXml.gx, m.gz = kXml.gz;
+    m.gear = kXml.gear;
+    m.x_lo = kXml.x_lo, m.x_hi = kXml.x_hi, m.margin = kXml.margin;
     // dof_invweight0 of the slider: (M^-1)_xx at qpos0 (both poles upright)
     const double a = m.mtot, b = m.s1z, c = m.s2z, d = m.diag1, e = L1 * m.s2z, f = m.diag2;
     const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
     m.invw = (d * f - e * e) / det;
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.95;             // default solref (.02 1), solimp (.9 .95 .001)
+    const double tc = kXml.solref_tc < 2 * dt ? 2 * dt : kXml.solref_tc, dmax = kXml.dmax;
     m.K = 1.0 / (dmax * dmax * tc * tc), m.B = 2.0 / (dmax * tc);
-    m.dmin = 0.9, m.dmax = dmax, m.width = 0.001;
+    m.dmin = kXml.dmin, m.dmax = dmax, m.width = kXml.width;
     m.dt = dt;
     m.phi_off = swingup ? M_PI : 0.0;                                         // _update_model: body_quat[2] = (0,0,1,0)
     return m;
+}
+
+// emei_model_constants (include/emei_hip.h): [gx, gz, mc, mp, Ip, lc, L1, gear, ctrl_lo, ctrl_hi, x_lo, x_hi, margin, solref tc,
+// solimp dmin, dmax, width]
+inline int xml_constants(double* out) {
+    const double mc = host::capsule_mass(kXml.rho, kXml.cart_r, kXml.cart_half), mp = host::capsule_mass(kXml.rho, kXml.pole_r, kXml.pole_half);
+    const double v[17] = {kXml.gx, kXml.gz, mc, mp, host::capsule_inertia_perp(kXml.rho, kXml.pole_r, kXml.pole_half), kXml.pole_half,
+                          kXml.L1, kXml.gear, kXml.ctrl_lo, kXml.ctrl_hi, kXml.x_lo, kXml.x_hi, kXml.margin, kXml.solref_tc, kXml.dmin,
+                          kXml.dmax, kXml.width};
+    for (int i = 0; i < 17; ++i) out[i] = v[i];
+    return 17;
 }
 
 }  // namespace dpend
@@ -68,6 +91,7 @@ struct DPendBody {
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kUnrollRK4 = false;
     static constexpr int kScratchPerLane = 0;
+    static constexpr bool kHasCtrlCost = false;
     static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 6, NO = 6, NA = 1;
@@ -86,7 +110,7 @@ struct DPendBody {
         const R S1x = (R)m.s1z * s1, S1z = (R)m.s1z * c1, S2x = (R)m.s2z * s2, S2z = (R)m.s2z * c2;
         const R Dx = (R)m.L1 * s1, Dz = (R)m.L1 * c1;
         const R M12 = fma_r(Dx, S2x, Dz * S2z);  // D . S2
-        const R u = ctrl[0] < R(-1) ? R(-1) : (ctrl[0] > R(1) ? R(1) : ctrl[0]);
+        const R u = ctrl[0] < R(dpend::kXml.ctrl_lo) ? R(dpend::kXml.ctrl_lo) : (ctrl[0] > R(dpend::kXml.ctrl_hi) ? R(dpend::kXml.ctrl_hi) : ctrl[0]);
         const R w1s = w1 * w1, w2s = w2 * w2;
         R fx = (R)m.gear * u + (R)m.mtot * (R)m.gx + w1s * S1x + w2s * S2x;
         R f1 = (R)m.gx * S1z + (R)m.gz * S1x + w2s * fma_r(S2x, Dz, -(S2z * Dx));  // S2 . perp(D)
@@ -169,7 +193,8 @@ struct DPendBody {
         o[0] = (double)s[0], o[1] = (double)quirk_wrap(s[1]), o[2] = (double)quirk_wrap(s[2]);
         o[3] = (double)s[3], o[4] = (double)s[4], o[5] = (double)s[5];
     }
-    __device__ __forceinline__ static double batch_reward(const float* obs, const float*, const float*, const Model& m, int) {
+    template <typename T>
+    __device__ __forceinline__ static double batch_reward(const T* obs, const T*, const T*, const Model& m, int) {
         double o[NO], rew;
         bool term;
 #pragma unroll
@@ -177,7 +202,8 @@ struct DPendBody {
         reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return rew;
     }
-    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
+    template <typename T>
+    __device__ __forceinline__ static bool batch_terminal(const T* obs, const Model& m) {
         double o[NO], rew;
         bool term;
 #pragma unroll

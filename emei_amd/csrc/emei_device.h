@@ -23,11 +23,14 @@ constexpr int kWave = 64;
 //   19 substeps (waves)   20 ... that run the slider-limit block   21 lanes beyond the rail
 #ifdef EMEI_NEWTON_STATS
 static __device__ unsigned long long g_debug_stats[32];
+// Branch-free on purpose: one atomic per ACTIVE lane with an addend of 1 (LANE) or of 1 for the first active lane and 0 for the
+// others (WAVE).  Build the variant with `-mllvm -amdgpu-atomic-optimizer-strategy=None` (tools/build_variant.sh does it for
+// -DEMEI_NEWTON_STATS): LLVM's atomic optimizer otherwise rewrites each atomic as "one lane adds the wave's sum" behind an
+// s_and_saveexec, and round 2's statistics build of the Hopper RK4 kernel was MISCOMPILED at exactly such a join (spill
+// stores in front of the EXEC restore: every lane but one per wave went non-finite; profiles/r03_hopper_rk4_stats_diag.txt).
 #define EMEI_STAT_LANE(i) atomicAdd(&emei::g_debug_stats[i], 1ull)
-#define EMEI_STAT_WAVE(i)                                                                                          \
-    do {                                                                                                           \
-        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&emei::g_debug_stats[i], 1ull); \
-    } while (0)
+#define EMEI_STAT_WAVE(i) \
+    atomicAdd(&emei::g_debug_stats[i], (unsigned long long)((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1))
 #else
 #define EMEI_STAT_LANE(i) ((void)0)
 #define EMEI_STAT_WAVE(i) ((void)0)
@@ -65,16 +68,23 @@ __device__ __forceinline__ void sincos_fast_r(float x, float& s, float& c) { fas
 // plain `if (cold)` form compiles to `s_and_saveexec; s_cbranch_execnz COLD; JOIN: ...; s_or_b64 exec`, and hipcc may
 // put register spill stores at the top of JOIN, in front of the EXEC restore, where they execute with EXEC = 0 in every
 // normal step (the cheetah RK4 miscompile; tests/test_isa_guards.py audits the shipped kernels for it).
+// Round 3: inside the cold region the repair is computed by EVERY lane and SELECTED per lane — no `if (cold)`, hence no
+// s_and_saveexec / EXEC-restore join in the region at all (the same allocator bug struck a -DEMEI_NEWTON_STATS build at
+// such a join, tools/isa_scan.py shape (b)); the library's large-argument reduction loops run under their own masks.
 __device__ __forceinline__ void sincos_repair_r(double x, double& s, double& c) {
     const bool cold = fabs(x) > kFastTrigLimitF64;
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {
-        if (cold) ::sincos(x, &s, &c);
+        double s2, c2;
+        ::sincos(x, &s2, &c2);
+        s = cold ? s2 : s, c = cold ? c2 : c;
     }
 }
 __device__ __forceinline__ void sincos_repair_r(float x, float& s, float& c) {
     const bool cold = fabsf(x) > kFastTrigLimitF32;
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {
-        if (cold) ::sincosf(x, &s, &c);
+        float s2, c2;
+        ::sincosf(x, &s2, &c2);
+        s = cold ? s2 : s, c = cold ? c2 : c;
     }
 }
 template <typename T>
@@ -125,7 +135,8 @@ __device__ __forceinline__ double trig_arg(double x) {
     const bool cold = !(__builtin_fabs(x) <= kFastTrigLimitF64);
     double r = x;
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {  // wave-uniform entry: see sincos_repair_r
-        if (cold) r = trig_reduce_large(x);
+        const double red = trig_reduce_large(x);       // straight-line arithmetic: every lane computes it, cold lanes take it
+        r = cold ? red : x;
     }
     return r;
 }

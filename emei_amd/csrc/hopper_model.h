@@ -55,22 +55,48 @@ using cheetah::V2;
 
 // model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000),
 // evaluated at compile time like the cheetah's (cheetah_model.h:kGeom)
+// the XML-level tables (hand-typed from hopper.xml; pinned to the file by tests/test_model_constants.py through
+// emei_model_constants) and the capsule masses / inertias MuJoCo's compiler derives (inertiafromgeom, density 1000)
+constexpr double kCtrlLo = -1.0, kCtrlHi = 1.0;  // motors: ctrlrange="-1.0 1.0" (xml:37-39)
+constexpr double kSolrefTc = 0.02;               // geom solref ".02 1" (xml:6); joint limits: MuJoCo's default (.02 1)
+struct HopperLinks {
+    // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
+    // foot (0,.1) xml:29, leg (0,.6) :25, thigh (0,1.05) :21, torso (0,1.25) :17
+    double half[NL], rad[NL];                // capsules :30,26,22,18
+    cheetah::cheetah_host::H2 gc[NL];        // capsule centres, link frame
+    double gang[NL];                         // capsule axis: +z rotated by this angle about y (the foot lies along x)
+    cheetah::cheetah_host::H2 dvec[NL];      // link L's vector to the joint of link L-1
+    double torso_z, z_ref;                   // body pos z and rootz ref (:14,16)
+    double mass[NL], inertia[NL];
+};
+constexpr HopperLinks hopper_links() {
+    using namespace cheetah::cheetah_host;
+    HopperLinks K{{0.195, 0.25, 0.225, 0.2}, {0.06, 0.04, 0.05, 0.05}, {{0.065, 0}, {0, -0.25}, {0, -0.225}, {0, 0}},
+                  {M_PI / 2, 0, 0, 0}, {{0, 0}, {0, -0.5}, {0, -0.45}, {0, -0.2}}, 1.25, 1.25, {}, {}};
+    const double rho = 1000.0;
+    for (int b = 0; b < NL; ++b) {
+        K.mass[b] = capsule_mass(rho, K.rad[b], K.half[b]);
+        K.inertia[b] = capsule_inertia_perp(rho, K.rad[b], K.half[b]);
+    }
+    return K;
+}
+
+// model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000),
+// evaluated at compile time like the cheetah's (cheetah_model.h:kGeom)
 constexpr Model make_model(double dt) {
     using namespace cheetah::cheetah_host;
     Model m{};
-    const double rho = 1000.0, deg = M_PI / 180.0;
-    // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
-    // foot (0,.1) xml:29, leg (0,.6) :25, thigh (0,1.05) :21, torso (0,1.25) :17
-    const double half[NL] = {0.195, 0.25, 0.225, 0.2}, rad[NL] = {0.06, 0.04, 0.05, 0.05};  // capsules :30,26,22,18
-    const H2 gc[NL] = {{0.065, 0}, {0, -0.25}, {0, -0.225}, {0, 0}};     // capsule centres, link frame
-    const double gang[NL] = {M_PI / 2, 0, 0, 0};                          // foot capsule lies along x
-    const H2 dvec[NL] = {{0, 0}, {0, -0.5}, {0, -0.45}, {0, -0.2}};       // to the child joint
-    double mass[NL] = {}, inertia[NL] = {}, sub[NL] = {};
-    for (int b = 0; b < NL; ++b) {
-        mass[b] = capsule_mass(rho, rad[b], half[b]);
-        inertia[b] = capsule_inertia_perp(rho, rad[b], half[b]);
-        sub[b] = mass[b] + (b ? sub[b - 1] : 0.0);  // link b carries links 0..b-1
-    }
+    const double deg = M_PI / 180.0;
+    const HopperLinks K = hopper_links();
+    const double(&half)[NL] = K.half;
+    const double(&rad)[NL] = K.rad;
+    const H2(&gc)[NL] = K.gc;
+    const double(&gang)[NL] = K.gang;
+    const H2(&dvec)[NL] = K.dvec;
+    const double(&mass)[NL] = K.mass;
+    const double(&inertia)[NL] = K.inertia;
+    double sub[NL] = {};
+    for (int b = 0; b < NL; ++b) sub[b] = mass[b] + (b ? sub[b - 1] : 0.0);  // link b carries links 0..b-1
     for (int b = 0; b < NL; ++b) {
         const double carried = b ? sub[b - 1] : 0.0;
         m.sx[b] = mass[b] * gc[b].x + carried * dvec[b].x, m.sz[b] = mass[b] * gc[b].z + carried * dvec[b].z;
@@ -78,7 +104,7 @@ constexpr Model make_model(double dt) {
                     carried * (dvec[b].x * dvec[b].x + dvec[b].z * dvec[b].z);
         m.d[b][0] = dvec[b].x, m.d[b][1] = dvec[b].z;
     }
-    m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = 1.25 - 1.25;  // body pos z 1.25, rootz ref 1.25 (:16)
+    m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = K.torso_z - K.z_ref;  // body pos z 1.25, rootz ref 1.25 (:16)
     const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};  // :21,25,29
     for (int k = 0; k < 3; ++k) m.damp[k] = 1.0, m.arm[k] = 1.0, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = 200.0;  // :5,37-39
     const int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
@@ -91,7 +117,7 @@ constexpr Model make_model(double dt) {
         m.friction[g] = g == 3 ? 2.0 : 1.0;  // max(floor 1.0, geom .9 | 2.0) (:18,22,26,30)
     }
     m.margin = 0.001;  // :6
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02;  // solref (.02 1), refsafe
+    const double tc = kSolrefTc < 2 * dt ? 2 * dt : kSolrefTc;  // solref (.02 1), refsafe
     m.c_dmin = 0.8, m.c_dmax = 0.8, m.c_width = 0.01;  // geom solimp (.8 .8 .01) :6
     m.l_dmin = 0.9, m.l_dmax = 0.95, m.l_width = 0.001;  // MuJoCo's joint-limit defaults
     m.cK = 1.0 / (m.c_dmax * m.c_dmax * tc * tc), m.cB = 2.0 / (m.c_dmax * tc);
@@ -102,6 +128,32 @@ constexpr Model make_model(double dt) {
 
 // every dt-independent constant of the model, as compile-time immediates for the device code
 __device__ constexpr Model kGeom = make_model(0.002);
+
+// emei_model_constants (include/emei_hip.h), XML body order torso, thigh, leg, foot = chain order reversed
+inline int xml_constants(double* out) {
+    constexpr HopperLinks K = hopper_links();
+    constexpr Model m = make_model(0.002);
+    int n = 0;
+    out[n++] = m.gravity;
+    for (int b = NL - 1; b >= 0; --b) {  // body pos: the torso in the world, a child at its parent's vector to the child joint
+        const double px = b == NL - 1 ? 0.0 : K.dvec[b + 1].x, pz = b == NL - 1 ? K.torso_z : K.dvec[b + 1].z;
+        const double row[6] = {K.mass[b], K.gc[b].x, K.gc[b].z, K.inertia[b], px, pz};
+        for (double v : row) out[n++] = v;
+    }
+    for (int g = 0; g < 4; ++g) {  // geom order torso, thigh, leg, foot; body index in XML order
+        const double row[7] = {(double)g, m.geom_end[2 * g][0], m.geom_end[2 * g][1], m.geom_end[2 * g + 1][0], m.geom_end[2 * g + 1][1],
+                               m.radius[g], m.friction[g]};
+        for (double v : row) out[n++] = v;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const double row[6] = {0.0 /* no joint stiffness */, m.damp[k], m.arm[k], m.lo[k], m.hi[k], m.gear[k]};
+        for (double v : row) out[n++] = v;
+    }
+    const double tail[13] = {m.margin, kSolrefTc, m.c_dmin, m.c_dmax, m.c_width, kSolrefTc, m.l_dmin, m.l_dmax, m.l_width, kCtrlLo, kCtrlHi,
+                             K.z_ref, -1.0 /* leg hinges about -y */};
+    for (double v : tail) out[n++] = v;
+    return n;
+}
 
 // inverse weights at qpos0 (see cheetah_model.h:kDofInvWeight0): joints thigh, leg, foot; links in chain order foot, leg,
 // thigh, torso.  Generated by oracle/planar_oracle.c:set_invweights (oracle.planar_invweights("hopper")).
@@ -193,7 +245,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     constexpr int jc[3] = {L_THIGH, L_LEG, L_FOOT}, jp[3] = {L_TORSO, L_THIGH, L_LEG};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);  // ctrlrange +-1 (xml:37-39)
+        const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);  // ctrlrange +-1 (xml:37-39)
         const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] -= tau;
         f[jp[k]] += tau;
@@ -382,7 +434,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const R c = ctrl[k] < R(-1) ? R(-1) : (ctrl[k] > R(1) ? R(1) : ctrl[k]);
+        const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);
         const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
         f[jc[k]] -= tau;
         f[jp[k]] += tau;
@@ -576,6 +628,7 @@ struct HopperBody {
     static constexpr int kMinWavesPerEU = SOLVER == EMEI_SOLVER_SWEEP1 ? 2 : 1;
     static constexpr bool kUnrollRK4 = false;  // unrolled: the same time with the Newton solver (25.76 vs 25.73 ms), 4x the code
     static constexpr int kScratchPerLane = 0;
+    static constexpr bool kHasCtrlCost = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
     static constexpr int NS = 12, NO = 12, NA = 3;
@@ -630,7 +683,15 @@ struct HopperBody {
 #pragma unroll
         for (int k = 0; k < NS; ++k) o[k] = (double)s[k];
     }
-    __device__ __forceinline__ static double batch_reward(const float* obs, const float* pre_obs, const float* act,
+    template <typename T>
+    __device__ __forceinline__ static double ctrl_cost(const T* act) {  // this row's sum a^2, float64 (hopper.py:98)
+        double cost = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) cost += (double)act[k] * (double)act[k];
+        return cost;
+    }
+    template <typename T>
+    __device__ __forceinline__ static double batch_reward(const T* obs, const T* pre_obs, const T* act,
                                                           const Model& m, int freq_rate) {
         double o[NO], cost = 0.0, rew;
         bool term;
@@ -641,7 +702,8 @@ struct HopperBody {
         reward_terminal(o, (double)pre_obs[0], cost, m, freq_rate, rew, term);
         return rew;
     }
-    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
+    template <typename T>
+    __device__ __forceinline__ static bool batch_terminal(const T* obs, const Model& m) {
         double o[NO], rew;
         bool term;
 #pragma unroll

@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "emei_device.h"
+#include "pendulum_envs.h"
 
 namespace emei {
 namespace ipend {
@@ -37,20 +38,17 @@ inline double capsule_inertia_perp(double rho, double r, double half) {
 inline Model make_model(bool swingup, double dt) {
     Model m;
     memset(&m, 0, sizeof(m));
-    const double rho = 1000.0, g = 9.81;
-    const double mc = host::capsule_mass(rho, 0.1, 0.1);
-    const double fx = 0.001, fz = 0.6, len = std::sqrt(fx * fx + fz * fz);
-    const double mp = host::capsule_mass(rho, 0.049, len / 2), Icom = host::capsule_inertia_perp(rho, 0.049, len / 2);
-    const double r = len / 2, phi0 = std::atan2(fx, fz);
+    constexpr IpModel x = ip_make_model(false);  // pendulum_envs.h: the one typed copy of the XML's numbers
+    const double g = x.gravity, mc = x.mc, mp = x.mp, Icom = x.Icom, r = x.r, phi0 = x.phi0;
     m.M11 = mc + mp, m.M22 = Icom + mp * r * r, m.mpr = mp * r, m.mgr = mp * g * r;
-    m.gear = 100.0, m.ctrl_lo = -3.0, m.ctrl_hi = 3.0, m.x_lo = -2.0, m.x_hi = 2.0;
+    m.gear = x.gear, m.ctrl_lo = x.ctrl_lo, m.ctrl_hi = x.ctrl_hi, m.x_lo = x.x_lo, m.x_hi = x.x_hi;
     m.phi_off = phi0 + (swingup ? M_PI : 0.0);  // _update_model: pole body turned by pi about y (:135-137)
     m.sin_off = std::sin(m.phi_off), m.cos_off = std::cos(m.phi_off);
     const double M12 = m.mpr * std::cos(phi0);
     m.invw = m.M22 / (m.M11 * m.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
-    const double tc = 0.02 < 2 * dt ? 2 * dt : 0.02, dmax = 0.95;  // default solref (.02 1) refsafe'd, solimp (.9 .95 .001)
+    const double tc = x.solref_tc < 2 * dt ? 2 * dt : x.solref_tc, dmax = x.dmax;  // default solref (.02 1) refsafe'd, solimp (.9 .95 .001)
     m.K = 1.0 / (dmax * dmax * tc * tc), m.B = 2.0 / (dmax * tc);
-    m.dmin = 0.9, m.dmax = dmax, m.width = 0.001;
+    m.dmin = x.dmin, m.dmax = dmax, m.width = x.width;
     m.dt = dt;
     return m;
 }
@@ -64,6 +62,7 @@ struct InvPendBody {
     static constexpr int kMinWavesPerEU = 1;
     static constexpr bool kUnrollRK4 = true;
     static constexpr int kScratchPerLane = 0;
+    static constexpr bool kHasCtrlCost = false;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = true;
     static constexpr int NS = 4, NO = 4, NA = 1;
@@ -129,13 +128,15 @@ struct InvPendBody {
     __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
         o[0] = (double)s[0], o[1] = (double)wrap(s[1]), o[2] = (double)s[2], o[3] = (double)s[3];
     }
-    __device__ __forceinline__ static double batch_reward(const float* obs, const float*, const float*, const Model& m, int) {
+    template <typename T>
+    __device__ __forceinline__ static double batch_reward(const T* obs, const T*, const T*, const Model& m, int) {
         double o[NO] = {obs[0], obs[1], obs[2], obs[3]}, rew;
         bool term;
         reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });
         return rew;
     }
-    __device__ __forceinline__ static bool batch_terminal(const float* obs, const Model& m) {
+    template <typename T>
+    __device__ __forceinline__ static bool batch_terminal(const T* obs, const Model& m) {
         double o[NO] = {obs[0], obs[1], obs[2], obs[3]}, rew;
         bool term;
         reward_terminal(o, m, rew, term, [](double x, double& sn, double& cs) { sincos_r(x, sn, cs); });

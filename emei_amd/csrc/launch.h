@@ -18,7 +18,8 @@ struct PendLaunch {
     unsigned long long* done_mask = nullptr;
     const void* actions = nullptr;
     const void* trig = nullptr;  // device {sin,cos} table (emei_trig_table)
-    const float* obs_in = nullptr;
+    const void* obs_in = nullptr;  // stateless ops: [n,4] float32, or float64 when io_f64
+    int io_f64 = 0;                // stateless ops: obs_in / obs_out / reward_out are float64 (EMEI_IO_F64)
     const int64_t* env_index = nullptr;  // PEND_OP_INIT_OBS
     const uint32_t* episode_in = nullptr;
     float* obs_out = nullptr;

@@ -117,9 +117,12 @@ struct CartPole {
 
     // reward / terminal from the carry of the NEW state
     __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const Params&) {
-        if (VARIANT == 0) return (R)__builtin_fmaf((float)c.cs, 0.5f, 0.5f);  // (cos+1)/2, cartpole.py:149-151
+        // (cos+1)/2, cartpole.py:149-151, in the working precision: near the hanging position cos -> -1 and the sum cancels —
+        // formed in float32 (round 2) the reward lost up to 3e-8 ABSOLUTE, i.e. 2e-5 relative at reward 5e-4
+        if (VARIANT == 0) return fma_r(c.cs, R(0.5), R(0.5));
         return R(1);                                     // cartpole.py:128-129
     }
+    __device__ __forceinline__ static R reward_exact(const R o[4], const Carry& c, const Params& p) { return reward(o, c, p); }
     __device__ __forceinline__ static bool terminal(const R o[4], const Carry&, const Params&) {
         if (VARIANT == 0) {
             bool notdone = fabs(o[0]) < R(5);  // cartpole.py:140,145-147
@@ -168,6 +171,11 @@ struct IpModel {
     double M11, M22, M11M22, mpr, inv_mpr, gravity, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
     double phi_off, sin_off, cos_off;  // phi = theta + phi_off is the angle of the pole's com from +z
     double invw, dmin, dmax, inv_width;
+    // what the XML's geoms compile to (inertiafromgeom, density 1000): cart mass, pole mass, pole inertia about its com, com
+    // distance from the hinge, tilt of the pole's axis at theta = 0 (fromto 0 0 0 0.001 0 0.6); the default solref time constant.
+    // THE one hand-typed copy of inverted_pendulum.xml on the kernel side: ipend_model.h and abi.hip:pend_params read these
+    // fields, emei_model_constants exports them, tests/test_model_constants.py pins them to the file.
+    double mc, mp, Icom, r, phi0, solref_tc, width;
 };
 constexpr IpModel ip_make_model(bool swingup) {
     IpModel m{};
@@ -188,10 +196,21 @@ constexpr IpModel ip_make_model(bool swingup) {
     m.sin_off = ce::sin(m.phi_off), m.cos_off = ce::cos(m.phi_off);
     const double M12 = m.mpr * ce::cos(phi0);
     m.invw = m.M22 / (m.M11 * m.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
-    m.dmin = 0.9, m.dmax = 0.95, m.inv_width = 1.0 / 0.001;  // default solimp (.9 .95 .001)
+    m.dmin = 0.9, m.dmax = 0.95, m.width = 0.001, m.inv_width = 1.0 / 0.001;  // default solimp (.9 .95 .001)
+    m.mc = mc, m.mp = mp, m.Icom = Icom, m.r = r, m.phi0 = phi0, m.solref_tc = 0.02;  // default solref (.02 1)
     return m;
 }
 __device__ constexpr IpModel kIpUpright = ip_make_model(false), kIpHanging = ip_make_model(true);
+
+// emei_model_constants (include/emei_hip.h): [gravity, mc, mp, Icom, r, phi0, gear, ctrl_lo, ctrl_hi, x_lo, x_hi, solref tc,
+// solimp dmin, dmax, width]
+inline int ip_xml_constants(double* out) {
+    constexpr IpModel m = ip_make_model(false);
+    const double v[15] = {m.gravity, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.solref_tc,
+                          m.dmin, m.dmax, m.width};
+    for (int i = 0; i < 15; ++i) out[i] = v[i];
+    return 15;
+}
 
 template <int VARIANT, typename R>
 struct InvPend {
@@ -324,6 +343,7 @@ struct InvPend {
         if (VARIANT >= 2) return (R(1) - cos_theta(c, p)) / R(2);  // inverted_pendulum.py:139-142,174-177
         return R(1);                                                // :73-74,103-104
     }
+    __device__ __forceinline__ static R reward_exact(const R o[4], const Carry& c, const Params& p) { return reward(o, c, p); }
     __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const Params& p) {
         bool fin = finite_r(o[0]) & finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
         bool inx = ((R)km().x_lo < o[0]) & (o[0] < (R)km().x_hi);

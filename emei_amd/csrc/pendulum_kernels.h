@@ -403,46 +403,73 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---------------------------------------------------------------------------------------------
-// stateless batched functions on float32 [n,4] observations
-// get_batch_reward / get_batch_terminal (core.py:182-188)
-template <class Env>
+// stateless batched functions on [n,4] observations of the caller's dtype T (float or double: emei_io_dtype)
+// get_batch_reward / get_batch_terminal (core.py:182-188).  float64 rows are not narrowed: the reference evaluates
+// these functions on float64 arrays (cartpole.py:124-129,145-151; inverted_pendulum.py:73-183)
+template <typename T>
+__device__ __forceinline__ void load_row4(const T* base, int64_t i, T (&v)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 x = ((const float4*)base)[i];
+        v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+    } else {
+        const double2 x = ((const double2*)base)[2 * i], y = ((const double2*)base)[2 * i + 1];
+        v[0] = x.x, v[1] = x.y, v[2] = y.x, v[3] = y.y;
+    }
+}
+template <typename T, typename R>
+__device__ __forceinline__ void store_row4(T* base, int64_t i, const R (&o)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        ((float4*)base)[i] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+    } else {
+        ((double2*)base)[2 * i] = make_double2((double)o[0], (double)o[1]);
+        ((double2*)base)[2 * i + 1] = make_double2((double)o[2], (double)o[3]);
+    }
+}
+
+template <class Env, typename T>
 __global__ void __launch_bounds__(kBlock)
-    pend_reward_terminal_kernel(const float4* obs, float* reward, uint8_t* terminal, int64_t n,
+    pend_reward_terminal_kernel(const T* obs, T* reward, uint8_t* terminal, int64_t n,
                                 typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
     stage_trig_table(trig_s, trig, Env::trig_scale());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    float4 v = obs[i];
-    R o[4] = {(R)v.x, (R)v.y, (R)v.z, (R)v.w};
+    T v[4];
+    load_row4(obs, i, v);
+    R o[4] = {(R)v[0], (R)v[1], (R)v[2], (R)v[3]};
     // the observation IS the state for reward/terminal purposes (wrapped angle has the same cosine);
     // build the carry from it.  For InvertedPendulum o[1] is theta, prime() adds phi_off itself.
     typename Env::Carry c;
     trig_ctx_init(c.trig, trig_s);
     Env::prime(o, c, p);
-    if (reward) reward[i] = (float)Env::reward(o, c, p);
+    if (reward) {
+        // float64 rows: the reward in the working precision (the fused kernels round it to the float32 they store)
+        if constexpr (sizeof(T) == 8) reward[i] = (T)Env::reward_exact(o, c, p);
+        else reward[i] = (T)Env::reward(o, c, p);
+    }
     if (terminal) terminal[i] = (uint8_t)Env::terminal(o, c, p);
 }
 
 // get_batch_next_obs (core.py:190-193): one step from caller-supplied observations
-template <class Env>
+template <class Env, typename T>
 __global__ void __launch_bounds__(kBlock)
-    pend_next_obs_kernel(const float4* obs, const void* actions, int action_dtype, float4* next_obs, int64_t n,
+    pend_next_obs_kernel(const T* obs, const void* actions, int action_dtype, T* next_obs, int64_t n,
                          int freq_rate, typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
     stage_trig_table(trig_s, trig, Env::trig_scale());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    float4 v = obs[i];
-    R s[4] = {(R)v.x, (R)v.y, (R)v.z, (R)v.w}, o[4], rew;
+    T v[4];
+    load_row4(obs, i, v);
+    R s[4] = {(R)v[0], (R)v[1], (R)v[2], (R)v[3]}, o[4], rew;
     bool term;
     typename Env::Carry c;
     trig_ctx_init(c.trig, trig_s);
     Env::prime(s, c, p);
     Env::step(s, c, Env::load_action(actions, action_dtype, i), p, freq_rate, o, rew, term);
-    next_obs[i] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+    store_row4(next_obs, i, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -523,12 +550,20 @@ static int launch_env(const PendLaunch& L) {
                                L.obs_f64, L.n);
             break;
         case PEND_OP_REWARD_TERMINAL:
-            hipLaunchKernelGGL(pend_reward_terminal_kernel<Env>, grid, dim3(kBlock), 0, L.stream,
-                               (const float4*)L.obs_in, L.reward_out, L.done_out, L.n, a.p, a.trig);
+            if (L.io_f64)
+                hipLaunchKernelGGL((pend_reward_terminal_kernel<Env, double>), grid, dim3(kBlock), 0, L.stream,
+                                   (const double*)L.obs_in, (double*)L.reward_out, L.done_out, L.n, a.p, a.trig);
+            else
+                hipLaunchKernelGGL((pend_reward_terminal_kernel<Env, float>), grid, dim3(kBlock), 0, L.stream,
+                                   (const float*)L.obs_in, (float*)L.reward_out, L.done_out, L.n, a.p, a.trig);
             break;
         case PEND_OP_NEXT_OBS:
-            hipLaunchKernelGGL(pend_next_obs_kernel<Env>, grid, dim3(kBlock), 0, L.stream, (const float4*)L.obs_in,
-                               L.actions, L.action_dtype, (float4*)L.obs_out, L.n, L.freq_rate, a.p, a.trig);
+            if (L.io_f64)
+                hipLaunchKernelGGL((pend_next_obs_kernel<Env, double>), grid, dim3(kBlock), 0, L.stream, (const double*)L.obs_in,
+                                   L.actions, L.action_dtype, (double*)L.obs_out, L.n, L.freq_rate, a.p, a.trig);
+            else
+                hipLaunchKernelGGL((pend_next_obs_kernel<Env, float>), grid, dim3(kBlock), 0, L.stream, (const float*)L.obs_in,
+                                   L.actions, L.action_dtype, (float*)L.obs_out, L.n, L.freq_rate, a.p, a.trig);
             break;
         default: return EMEI_ERR_INVALID;
     }

@@ -272,34 +272,53 @@ class Engine:
 
 
 # -- stateless batched functions -----------------------------------------------------------------
-def _f32c(t, device):
-    return None if t is None else torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+def _rows(t, device, dtype=None):
+    """caller's array -> contiguous device tensor; float64 stays float64 (the reference evaluates these functions on float64
+    arrays: cartpole.py:124-129,145-151; half_cheetah.py:59-67), anything else becomes float32"""
+    if t is None:
+        return None
+    t = torch.as_tensor(t, device=device)
+    if dtype is None:
+        dtype = torch.float64 if t.dtype == torch.float64 else torch.float32
+    return t.to(dtype).contiguous()
 
 
-def batch_reward(env_name, obs, pre_obs=None, action=None, real_time_scale=0.02, freq_rate=1, env_params=None):
-    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
-    pre_obs, action = _f32c(pre_obs, obs.device), _f32c(action, obs.device)
-    out = torch.empty(obs.shape[0], dtype=torch.float32, device=obs.device)
+def _io(t):
+    return L.IO_F64 if t.dtype == torch.float64 else L.IO_F32
+
+
+def batch_reward(env_name, obs, pre_obs=None, action=None, real_time_scale=0.02, freq_rate=1, env_params=None,
+                 batch_ctrl_cost=False):
+    """get_batch_reward on [B, obs_dim] rows -> [B] in the rows' dtype (float64 in -> float64 out, not narrowed).
+    batch_ctrl_cost: HalfCheetah / Hopper only — the control cost summed over the WHOLE batch, which is what
+    half_cheetah.py:61 / hopper.py:98 execute for B > 1 (np.sum without an axis)."""
+    obs = _rows(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    pre_obs, action = _rows(pre_obs, obs.device, obs.dtype), _rows(action, obs.device, obs.dtype)
+    out = torch.empty(obs.shape[0], dtype=obs.dtype, device=obs.device)
     mask, arr = L.pack_env_params(env_params)
-    L.check(L.lib().emei_reward_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(pre_obs), _ptr(action),
-                                   float(real_time_scale), int(freq_rate), mask, C.cast(arr, C.c_void_p), _ptr(out), _stream()))
+    with torch.cuda.device(obs.device):
+        L.check(L.lib().emei_reward_io(L.ENV_IDS[env_name], obs.shape[0], _io(obs), _ptr(obs), _ptr(pre_obs), _ptr(action),
+                                       float(real_time_scale), int(freq_rate), mask, C.cast(arr, C.c_void_p),
+                                       L.REWARD_BATCH_CTRL_COST if batch_ctrl_cost else 0, _ptr(out), _stream()))
     return out
 
 
 def batch_terminal(env_name, obs, env_params=None):
-    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    obs = _rows(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     out = torch.empty(obs.shape[0], dtype=torch.uint8, device=obs.device)
     mask, arr = L.pack_env_params(env_params)
-    L.check(L.lib().emei_terminal_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), mask, C.cast(arr, C.c_void_p), _ptr(out),
-                                     _stream()))
+    with torch.cuda.device(obs.device):
+        L.check(L.lib().emei_terminal_io(L.ENV_IDS[env_name], obs.shape[0], _io(obs), _ptr(obs), mask, C.cast(arr, C.c_void_p),
+                                         _ptr(out), _stream()))
     return out.bool()
 
 
 def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref", integrator="euler"):
-    obs = _f32c(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
+    obs = _rows(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     actions = actions.to(obs.device).contiguous()
     out = torch.empty_like(obs)
-    L.check(L.lib().emei_next_obs_ex(L.ENV_IDS[env_name], obs.shape[0], _ptr(obs), _ptr(actions), _ACT_DTYPES[actions.dtype],
-                                     float(real_time_scale), int(freq_rate), {"ref": 0, "f32": 1}[precision],
-                                     L.INTEGRATORS[integrator], _ptr(out), _stream()))
+    with torch.cuda.device(obs.device):
+        L.check(L.lib().emei_next_obs_io(L.ENV_IDS[env_name], obs.shape[0], _io(obs), _ptr(obs), _ptr(actions),
+                                         _ACT_DTYPES[actions.dtype], float(real_time_scale), int(freq_rate),
+                                         {"ref": 0, "f32": 1}[precision], L.INTEGRATORS[integrator], _ptr(out), _stream()))
     return out

@@ -194,22 +194,33 @@ class HipEnv(EmeiEnv):
             return out
         return out.cpu().numpy().astype(np_dtype)
 
-    def get_batch_reward(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
+    def _rows_to_dev(self, x, like=None):
+        """caller's rows -> device tensor: float64 (NumPy's default, what the reference computes on) stays float64, everything
+        else becomes float32; `like` forces the dtype of the observation rows on pre_obs / action"""
         import torch
 
+        if x is None:
+            return None
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        want = like.dtype if like is not None else (torch.float64 if t.dtype == torch.float64 else torch.float32)
+        return t.to(device=self.engine.device, dtype=want)
+
+    # whole-batch control cost of half_cheetah.py:61 / hopper.py:98 (np.sum without an axis): opt-in per call or per env
+    reference_batch_semantics = False
+
+    def get_batch_reward(self, obs, pre_obs=None, action=None, state=None, pre_state=None, reference_batch_semantics=None):
         from .. import engine as E
 
-        o = self._to_dev(obs, torch.float32)
-        r = E.batch_reward(self.ENGINE_NAME, o, self._to_dev(pre_obs, torch.float32), self._to_dev(action, torch.float32),
-                           self.real_time_scale, self.freq_rate, self._engine_env_params)
+        o = self._rows_to_dev(obs)
+        whole = self.reference_batch_semantics if reference_batch_semantics is None else bool(reference_batch_semantics)
+        r = E.batch_reward(self.ENGINE_NAME, o, self._rows_to_dev(pre_obs, o), self._rows_to_dev(action, o),
+                           self.real_time_scale, self.freq_rate, self._engine_env_params, batch_ctrl_cost=whole)
         return self._like(r, obs, np.float64)
 
     def get_batch_terminal(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
-        import torch
-
         from .. import engine as E
 
-        t = E.batch_terminal(self.ENGINE_NAME, self._to_dev(obs, torch.float32), self._engine_env_params)
+        t = E.batch_terminal(self.ENGINE_NAME, self._rows_to_dev(obs), self._engine_env_params)
         return self._like(t, obs, np.bool_)
 
     def get_batch_next_obs(self, obs, pre_obs=None, action=None, state=None, pre_state=None):
@@ -220,7 +231,7 @@ class HipEnv(EmeiEnv):
         from .. import engine as E
 
         assert self.frozen
-        o = self._to_dev(obs, torch.float32)
+        o = self._rows_to_dev(obs)
         a = self._to_dev(action)
         if self.engine.act_dim == 0:
             a = a.reshape(-1).to(torch.int64)

@@ -22,7 +22,11 @@
 extern "C" {
 #endif
 
-#define EMEI_ABI_VERSION 2
+/* ABI history.  1: emei_config of 64 B.  2: integrator / noise layout / per-coordinate sigmas (328 B), env_params (400 B),
+ * emei_set_seed, emei_last_rollout_kernel, emei_config.solver (the former reserved0; reserved words MUST be zero).
+ * 3: the *_io stateless entry points (float64 observations), emei_freeze / emei_unfreeze snapshot the reset key,
+ *    emei_model_constants, emei_solver_cap_hits. */
+#define EMEI_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -151,6 +155,22 @@ EMEI_API int emei_destroy(emei_env* h);
 EMEI_API const char* emei_last_error(void);
 EMEI_API int emei_abi_version(void);
 
+/* Debug / test getter: the model constants the kernels of `env_id` are COMPILED from, in physical terms, so that a test
+ * can pin them to the reference's only data for the MuJoCo-backed bodies (the XML files under emei/envs/mujoco/assets;
+ * tests/test_model_constants.py).  Writes at most `capacity` doubles to `out`, returns the count (negative = error;
+ * EMEI_ERR_UNSUPPORTED for the classic-control CartPole, whose constants are cartpole.py:22-27 literals).  Host only.
+ *   InvertedPendulum x4 (15): gravity, cart mass, pole mass, pole inertia about its com, com distance from the hinge, tilt of
+ *       the pole axis at theta = 0, gear, ctrlrange lo, hi, slider range lo, hi, limit solref time constant, solimp dmin, dmax, width
+ *   InvertedDoublePendulum x4 (17): gravity x, gravity z, cart mass, pole mass, pole inertia about its com, pole com distance,
+ *       pole-1 length, gear, ctrlrange lo, hi, slider range lo, hi, joint margin, limit solref time constant, solimp dmin, dmax, width
+ *   HalfCheetahRunning (148) / HopperRunning (84), nb = 7 / 4 bodies, ng = 8 / 4 capsules, nj = 6 / 3 actuated hinges:
+ *       gravity; per body in XML order {mass, com x, com z (body frame), inertia about the com, origin x, origin z (parent frame;
+ *       root: world)}; per capsule in XML order {body, end-sphere centre 0 x, z, centre 1 x, z (body frame), radius, pair friction
+ *       with the floor}; per actuated joint {stiffness, damping, armature, range lo, hi (rad), gear}; contact margin, contact
+ *       solref time constant, solimp dmin, dmax, width, limit solref time constant, solimp dmin, dmax, width, ctrlrange lo, hi,
+ *       rootz ref, sign of the leg hinges' axis (+1: +y, -1: -y) */
+EMEI_API int emei_model_constants(int env_id, double* out, int capacity);
+
 /* Static facts about an env id: obs_dim, act_dim (0 = discrete scalar action), state_dim. */
 EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, int* state_dim);
 
@@ -241,6 +261,22 @@ EMEI_API int emei_reward_ex(int env_id, int64_t n, const float* obs, const float
 EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t env_param_mask, const double* env_params,
                      uint8_t* terminal_out, void* stream);
 
+/* The same three functions on the dtype the CALLER holds (enum emei_io_dtype).  The reference evaluates
+ * get_batch_reward / get_batch_terminal on float64 arrays (cartpole.py:124-129,145-151; inverted_pendulum.py:73-183;
+ * half_cheetah.py:59-67; hopper.py:95-106): with EMEI_IO_F64 obs / pre_obs / action are float64 [n, dim] and are
+ * NOT narrowed — thresholds (|x| < 5, x_l < x < x_r, z ranges) and the x-difference of the forward reward are evaluated
+ * on the caller's float64 values; reward_out is float64 [n].  EMEI_IO_F32 is the float32 form above. */
+enum emei_io_dtype { EMEI_IO_F32 = 0, EMEI_IO_F64 = 1 };
+/* flags of emei_reward_io */
+#define EMEI_REWARD_BATCH_CTRL_COST 1u /* HalfCheetahRunning only: the control cost is np.sum(np.square(action)) over the
+                                          WHOLE batch, as half_cheetah.py:61 executes for B > 1 (no axis argument); the
+                                          default (0) sums per env = step() semantics */
+EMEI_API int emei_reward_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* pre_obs, const void* action,
+                   double real_time_scale, int32_t freq_rate, uint32_t env_param_mask, const double* env_params,
+                   uint32_t flags, void* reward_out, void* stream);
+EMEI_API int emei_terminal_io(int env_id, int64_t n, int io_dtype, const void* obs, uint32_t env_param_mask,
+                     const double* env_params, uint8_t* terminal_out, void* stream);
+
 /* EmeiEnv.get_batch_next_obs (core.py:190-193; abstract in the reference, no env implements it):
  * one step from caller-supplied float32 observations without touching any handle state.
  * obs [n, obs_dim], action as in emei_step, next_obs_out [n, obs_dim]. */
@@ -255,6 +291,12 @@ EMEI_API int emei_next_obs(int env_id, int64_t n, const float* obs, const void* 
 EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const void* actions, int action_dtype,
                      double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
                      float* next_obs_out, void* stream);
+
+/* emei_next_obs_ex on the caller's dtype: obs and next_obs_out are [n, obs_dim] of io_dtype (float64 observations enter the
+ * float64 state unrounded); actions as in emei_step. */
+EMEI_API int emei_next_obs_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* actions, int action_dtype,
+                     double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
+                     void* next_obs_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,16 @@ EXPORT void dpend_oracle_model(dp_model_t* m, double dt) {
     m->invw = w[0]; /* dof_invweight0 of the slider at qpos0 (compiled model: poles upright) */
 }
 
+/* the oracle's constants in the layout of emei_model_constants (include/emei_hip.h); tests/test_model_constants.py */
+EXPORT int dpend_oracle_xml_constants(double* out) {
+    dp_model_t m;
+    dpend_oracle_model(&m, 0.002);
+    const double v[17] = {m.gx, m.gz, m.mc, m.mp, m.Ip, m.lc, m.L1, m.gear, -1.0 /* ctrl clamp of dp_accel */, 1.0, m.x_lo, m.x_hi,
+                          m.margin, m.tc /* at dt = 0.002: the unclamped default */, m.dmin, m.dmax, m.width};
+    memcpy(out, v, sizeof(v));
+    return 17;
+}
+
 typedef struct { const dp_model_t* m; double off; } dp_ctx_t;
 /* forward dynamics (no joint damping: hd unused); integrators in integrators.h */
 static void dp_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl_in, double* acc) {

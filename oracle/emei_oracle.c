@@ -246,6 +246,17 @@ EXPORT void emei_oracle_ip_model(ip_model_t* m) {
 
 EXPORT int emei_oracle_ip_model_size(void) { return (int)sizeof(ip_model_t); }
 
+/* the oracle's InvertedPendulum constants in the layout of emei_model_constants (include/emei_hip.h), for
+ * tests/test_model_constants.py, which pins them to the reference's XML */
+EXPORT int emei_oracle_ip_xml_constants(double* out) {
+    ip_model_t m;
+    emei_oracle_ip_model(&m);
+    const double v[15] = {m.g, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.timeconst,
+                          m.dmin, m.dmax, m.width};
+    memcpy(out, v, sizeof(v));
+    return 15;
+}
+
 static inline int ip_is_swingup(int variant) { return variant >= 2; }
 static inline int ip_is_rebound(int variant) { return (variant & 1) == 0; }
 

@@ -460,6 +460,8 @@ def gen_hopper_firstparty(ref, out):
         # step() semantics: B = 1 per call (np.sum(np.square(action)) has no axis, hopper.py:98)
         data["hopper_reward_B1"] = np.stack([cls.get_batch_reward(f, o[i : i + 1].copy(), po[i : i + 1], a[i : i + 1])[0, 0] for i in range(B)])
         data["hopper_terminal"] = np.asarray(cls.get_batch_terminal(f, o.copy()))
+        # what get_batch_reward EXECUTES for B > 1: the control cost of the whole batch in every row (hopper.py:98)
+        data["hopper_reward_batchquirk"] = np.asarray(cls.get_batch_reward(f, o.copy(), po, a))
         # the reference's own test inputs (test_hopper.py:9-13)
         data["hopper_is_healthy_ones"] = np.asarray(cls.is_healthy(f, np.ones([128, 12])))
         data["hopper_is_healthy_101"] = np.asarray(cls.is_healthy(f, np.ones([128, 12]) * 101))
@@ -546,6 +548,96 @@ def gen_lagrange(ref_root, out):
     return data
 
 
+# --------------------------------------------------------------------------- model constants (XML data)
+def gen_model_constants(ref_root, out):
+    """The reference's only data for the MuJoCo-backed bodies: emei/envs/mujoco/assets/{inverted_pendulum,
+    inverted_double_pendulum,half_cheetah,hopper}.xml, parsed with xml.etree into flat numeric arrays (defaults of
+    <default> resolved, nothing derived).  tests/test_model_constants.py derives masses / inertias / link-frame geometry
+    from these arrays with MuJoCo's documented compiler rules and compares the oracle's tables and the kernels'
+    compile-time tables with them, so that a mistyped constant on either side is found (missing #4).
+    Entries the XML does not state are NaN (the consumer applies MuJoCo's documented default)."""
+    import xml.etree.ElementTree as ET
+
+    def nums(txt, n=None):
+        v = [float(x) for x in txt.split()] if txt is not None else []
+        if n is not None:
+            v = (v + [np.nan] * n)[:n]
+        return v
+
+    data = {}
+    for tag, fname in (("ip", "inverted_pendulum.xml"), ("dp", "inverted_double_pendulum.xml"), ("ch", "half_cheetah.xml"),
+                       ("hp", "hopper.xml")):
+        root = ET.parse(os.path.join(ref_root, "emei", "envs", "mujoco", "assets", fname)).getroot()
+        comp, opt = root.find("compiler"), root.find("option")
+        dflt = root.find("default")
+        dj = dict(dflt.find("joint").attrib) if dflt is not None and dflt.find("joint") is not None else {}
+        dg = dict(dflt.find("geom").attrib) if dflt is not None and dflt.find("geom") is not None else {}
+        dm = dict(dflt.find("motor").attrib) if dflt is not None and dflt.find("motor") is not None else {}
+        data[f"{tag}_angle_degree"] = np.array(comp.get("angle", "degree") == "degree")  # MuJoCo's default unit is degree
+        data[f"{tag}_coordinate_global"] = np.array(comp.get("coordinate", "local") == "global")
+        data[f"{tag}_settotalmass"] = np.array(float(comp.get("settotalmass", "nan")))
+        data[f"{tag}_gravity"] = np.array(nums(opt.get("gravity"), 3))
+        data[f"{tag}_timestep"] = np.array(float(opt.get("timestep", "nan")))
+        bodies, joints, geoms = [], [], []
+
+        def walk(el, parent):
+            for child in el:
+                if child.tag == "body":
+                    bodies.append((child.get("name"), parent, nums(child.get("pos"), 3), nums(child.get("quat"), 4)))
+                    walk(child, len(bodies) - 1)
+                elif child.tag == "joint":
+                    a = dict(dj)
+                    a.update(child.attrib)
+                    joints.append((a.get("name"), parent, a))
+                elif child.tag == "geom":
+                    a = dict(dg)
+                    a.update(child.attrib)
+                    geoms.append((a.get("name"), parent, a))
+
+        walk(root.find("worldbody"), -1)
+        data[f"{tag}_body_names"] = np.array([b[0] for b in bodies])
+        data[f"{tag}_body_parent"] = np.array([b[1] for b in bodies])
+        data[f"{tag}_body_pos"] = np.array([b[2] for b in bodies])
+        data[f"{tag}_body_quat"] = np.array([b[3] for b in bodies])
+        data[f"{tag}_joint_names"] = np.array([j[0] for j in joints])
+        data[f"{tag}_joint_body"] = np.array([j[1] for j in joints])
+        data[f"{tag}_joint_is_hinge"] = np.array([j[2].get("type", "hinge") == "hinge" for j in joints])
+        data[f"{tag}_joint_axis"] = np.array([nums(j[2].get("axis"), 3) for j in joints])
+        data[f"{tag}_joint_pos"] = np.array([nums(j[2].get("pos"), 3) for j in joints])
+        data[f"{tag}_joint_limited"] = np.array([j[2].get("limited", "false") == "true" for j in joints])
+        data[f"{tag}_joint_range"] = np.array([nums(j[2].get("range"), 2) for j in joints])
+        for key in ("stiffness", "damping", "armature", "margin", "ref"):
+            data[f"{tag}_joint_{key}"] = np.array([float(j[2].get(key, "nan")) for j in joints])
+        data[f"{tag}_joint_solreflimit"] = np.array([nums(j[2].get("solreflimit"), 2) for j in joints])
+        data[f"{tag}_joint_solimplimit"] = np.array([nums(j[2].get("solimplimit"), 3) for j in joints])
+        data[f"{tag}_geom_names"] = np.array([str(g[0]) for g in geoms])
+        data[f"{tag}_geom_body"] = np.array([g[1] for g in geoms])
+        data[f"{tag}_geom_is_capsule"] = np.array([g[2].get("type", "sphere") == "capsule" for g in geoms])
+        data[f"{tag}_geom_size"] = np.array([nums(g[2].get("size"), 3) for g in geoms])
+        data[f"{tag}_geom_fromto"] = np.array([nums(g[2].get("fromto"), 6) for g in geoms])
+        data[f"{tag}_geom_pos"] = np.array([nums(g[2].get("pos"), 3) for g in geoms])
+        data[f"{tag}_geom_axisangle"] = np.array([nums(g[2].get("axisangle"), 4) for g in geoms])
+        data[f"{tag}_geom_quat"] = np.array([nums(g[2].get("quat"), 4) for g in geoms])
+        data[f"{tag}_geom_friction"] = np.array([nums(g[2].get("friction"), 3) for g in geoms])
+        data[f"{tag}_geom_solref"] = np.array([nums(g[2].get("solref"), 2) for g in geoms])
+        data[f"{tag}_geom_solimp"] = np.array([nums(g[2].get("solimp"), 3) for g in geoms])
+        data[f"{tag}_geom_margin"] = np.array([float(g[2].get("margin", "nan")) for g in geoms])
+        data[f"{tag}_geom_condim"] = np.array([float(g[2].get("condim", "nan")) for g in geoms])
+        data[f"{tag}_geom_contype"] = np.array([float(g[2].get("contype", "nan")) for g in geoms])
+        jn = [j[0] for j in joints]
+        acts = []
+        for m_ in root.find("actuator"):
+            a = dict(dm)
+            a.update(m_.attrib)
+            acts.append((jn.index(a["joint"]), float(a.get("gear", "1")), nums(a.get("ctrlrange"), 2), a.get("ctrllimited", "false") == "true"))
+        data[f"{tag}_act_joint"] = np.array([a[0] for a in acts])
+        data[f"{tag}_act_gear"] = np.array([a[1] for a in acts])
+        data[f"{tag}_act_ctrlrange"] = np.array([a[2] for a in acts])
+        data[f"{tag}_act_ctrllimited"] = np.array([a[3] for a in acts])
+    np.savez_compressed(os.path.join(out, "model_constants_golden.npz"), **data)
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -558,12 +650,13 @@ def main():
     d = gen_dpend_firstparty(ref, a.out)
     h = gen_hopper_firstparty(ref, a.out)
     lg = gen_lagrange(a.ref, a.out)
+    mc = gen_model_constants(a.ref, a.out)
     env = ref.cp.CartPoleSwingUpEnv()
     o, _ = env.reset(seed=0)
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg))
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg), " model-constant keys:", len(mc))
 
 
 if __name__ == "__main__":

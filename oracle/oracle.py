@@ -343,6 +343,28 @@ def planar_solve_unit(body, q, v, ctrl, dt=0.002, warm=None, max_iter=24):
     return dict(a=a, passes=ps.value, nrows=nr.value)
 
 
+def planar_count_rows(body, state, dt=0.002):
+    """Scalar constraint rows of the solver at each state [n, 2 nv] (-1 for a non-finite state)."""
+    nv = 9 if body == "cheetah" else 6
+    st = np.ascontiguousarray(state, np.float64).reshape(-1, 2 * nv)
+    out = np.empty(len(st), np.int32)
+    lib().planar_oracle_count_rows(C.c_int(0 if body == "cheetah" else 1), C.c_int64(len(st)), C.c_double(dt), _p(st, C.c_double),
+                                   _p(out, C.c_int32))
+    return out
+
+
+def xml_constants(model):
+    """The oracle's model constants of "ip" | "dp" | "cheetah" | "hopper" in the layout of emei_model_constants."""
+    out = np.full(256, np.nan)
+    if model == "ip":
+        n = lib().emei_oracle_ip_xml_constants(_p(out, C.c_double))
+    elif model == "dp":
+        n = lib().dpend_oracle_xml_constants(_p(out, C.c_double))
+    else:
+        n = lib().planar_oracle_xml_constants(C.c_int(0 if model == "cheetah" else 1), _p(out, C.c_double))
+    return out[:n].copy()
+
+
 def planar_invweights(body):
     """(dof_invweight0 [nv], body_invweight0 [nb]) of the planar-tree oracle at qpos0 (mj_setConst)."""
     nv, nb = (9, 7) if body == "cheetah" else (6, 4)

@@ -206,6 +206,37 @@ EXPORT void hopper_oracle_model(planar_model_t* m) {
     set_invweights(m);
 }
 
+/* the oracle's tables in the layout of emei_model_constants (include/emei_hip.h): gravity; per body {mass, com, inertia,
+ * origin in the parent frame}; per capsule {body, two end-sphere centres, radius, pair friction}; per actuated joint
+ * {stiffness, damping, armature, range, gear}; margins / solref / solimp; ctrlrange; rootz ref; hinge sign.
+ * tests/test_model_constants.py pins them to the reference's XML. */
+EXPORT int planar_oracle_xml_constants(int body, double* out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    int n = 0;
+    out[n++] = m.gravity;
+    for (int b = 0; b < m.nb; ++b) {
+        out[n++] = m.mass[b], out[n++] = m.com[b].x, out[n++] = m.com[b].z, out[n++] = m.inertia[b];
+        out[n++] = m.body_pos[b].x, out[n++] = m.body_pos[b].z;
+    }
+    for (int g = 0; g < m.ng; ++g) {
+        out[n++] = m.geom_body[g];
+        out[n++] = m.geom_end[g][0].x, out[n++] = m.geom_end[g][0].z, out[n++] = m.geom_end[g][1].x, out[n++] = m.geom_end[g][1].z;
+        out[n++] = m.geom_radius[g], out[n++] = m.geom_friction[g];
+    }
+    for (int k = 0; k < m.nu; ++k) {
+        const int d = m.act_dof[k];
+        out[n++] = m.stiffness[d], out[n++] = m.damping[d], out[n++] = m.armature[d], out[n++] = m.range_lo[d], out[n++] = m.range_hi[d];
+        out[n++] = m.gear[k];
+    }
+    out[n++] = m.contact_margin;
+    out[n++] = m.c_tc, out[n++] = m.c_dmin, out[n++] = m.c_dmax, out[n++] = m.c_width;
+    out[n++] = m.l_tc, out[n++] = m.l_dmin, out[n++] = m.l_dmax, out[n++] = m.l_width;
+    out[n++] = -1.0, out[n++] = 1.0; /* the ctrl clamp of smooth_terms / planar_accel_sweep1 */
+    out[n++] = m.z_ref, out[n++] = m.hinge_sign[m.nb - 1];
+    return n;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * kinematics: absolute angle, origin and com of every body */
 typedef struct { double phi[NB]; v2 org[NB], com[NB]; } kin_t;
@@ -765,6 +796,24 @@ EXPORT void planar_oracle_solve_unit(int body, double dt, const double* q, const
     int it = 0;
     newton_solve_ex(nv, M, a0, nr, rows, a_out, &it, NULL, 1, warm, fm, max_iter);
     *passes = it + 1;
+}
+/* diagnostics for the long-horizon tests: number of scalar constraint rows (limit rows + 4 pyramid edges per contact point)
+ * the solver sees at each of n states [n, 2 nv] = (qpos, qvel); -1 for a non-finite state */
+EXPORT void planar_oracle_count_rows(int body, int64_t n, double dt, const double* state, int32_t* nrows_out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    const int nv = m.nv;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double* q = state + 2 * nv * i;
+        int finite = 1;
+        for (int c = 0; c < 2 * nv; ++c) finite &= isfinite(q[c]) != 0;
+        if (!finite) { nrows_out[i] = -1; continue; }
+        kin_t k;
+        kinematics(&m, q, &k);
+        crow_t rows[MAXROWS];
+        nrows_out[i] = build_rows(&m, &k, dt, q, q + nv, rows);
+    }
 }
 EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
     planar_model_t m;

@@ -48,6 +48,7 @@ def _check_common(j, n_gpus, steps, warmup):
         j["config"]["horizon"] // j["config"]["chunk_steps"])
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
     assert "pend_rollout_staged_kernel" in r["kernel"]
+    assert j["launch"]["ranks"] == n_gpus and len(j["launch"]["devices"]) == n_gpus
     assert r["traffic"] is None or "traffic_source" in r
 
 
@@ -63,13 +64,52 @@ def test_default_single_gpu_line():
     assert j["value"] > 1e7  # north_star's floor
 
 
-def test_two_rank_line_over_gloo_sharing_the_gpu():
+@pytest.mark.parametrize("how", ["direct", "under_launcher"])
+def test_two_rank_line_over_gloo_sharing_the_gpu(how):
+    """`python bench.py --gpus 2` exactly as the driver types it (bench.py starts its own ranks), and the same line when a
+    launcher already did (torch.distributed.run)."""
     steps, warmup = 3, 1
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29633", "bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup)]
-    j = _line(cmd, env={"EMEI_BENCH_SHARE_GPU": "1", "EMEI_BENCH_BACKEND": "gloo"}, timeout=600)
+    args = ["bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup)]
+    if how == "direct":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29633"] + args
+    env = {"EMEI_BENCH_SHARE_GPU": "1", "EMEI_BENCH_BACKEND": "gloo"}
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):  # the test itself may run under a launcher
+        e.pop(k, None)
+    e.update(env)
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-500:]
+    j = json.loads(lines[0])
     _check_common(j, 2, steps, warmup)
     cfg = j["config"]
     assert cfg["envs_per_gpu"] == 131072 and cfg["gather"] == "per_chunk" and cfg["chunk_steps"] == 125
     x = j["xgmi"]
     assert x["inbound_bytes_per_rank_per_pass"] == 131072 * 1000 * 16  # one peer's whole [T, n, 4] float32 return
+    assert x["peak"] == pytest.approx(7 * 153.6 / 2)  # inbound = half of the links' bidirectional rate
+    la = j["launch"]
+    assert la["ranks"] == 2 and la["backend"] == "gloo" and len(la["devices"]) == 2 and all(d.startswith("cuda:0") for d in la["devices"])
+    assert la["self_launched"] == (how == "direct")
+
+
+def test_a_failing_rank_fails_the_self_launched_bench():
+    """exit status of the launcher is relayed: an impossible workload size makes every rank raise"""
+    e = dict(os.environ, EMEI_BENCH_SHARE_GPU="1", EMEI_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--envs-per-gpu", "-5"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_other_workloads_carry_their_own_cpu_baseline():
+    """configs[2] / configs[3]: the CPU oracle of the SAME env kind is timed beside the GPU number (bounded sample)."""
+    for wl, frac in (("invpend", "InvertedPendulum"), ("cheetah", "HalfCheetahRunning")):
+        j = _line([sys.executable, "bench.py", "--workload", wl, "--steps", "3", "--warmup", "1"], timeout=600)
+        c = j["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and frac in c["sample"] and c["cores"] >= 1
+        assert j["launch"]["ranks"] == 1

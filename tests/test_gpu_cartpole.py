@@ -1,6 +1,6 @@
 """GPU parity of the CartPole kernels (through the C ABI) against the golden vectors generated from
 the reference and against the CPU oracle.  Tolerance (BASELINE.json north_star): 1e-5 relative on
-float32 trajectories (floor: |ref| < 1 is compared absolutely), terminal masks bit-exact."""
+float32 trajectories (relative down to |ref| = 1e-3, conftest.rel_err), terminal masks bit-exact."""
 import numpy as np
 import pytest
 
@@ -37,11 +37,13 @@ def test_onestep_vs_golden(cartpole_golden, name, fr, dt, precision, adtype):
     # REF (the default, float64 like the reference) meets the north-star 1e-5 on every row; the float32
     # fast mode is held to 1e-5 on states an episode visits and to 1e-4 on the |theta| ~ 600 rad rows,
     # where float32(theta) itself carries 3e-5 rad
-    tol = RTOL if precision == "ref" else 1e-4
-    assert rel_err(obs[ok], nxt[ok]) <= tol
-    assert rel_err(rew[ok], gr[ok]) <= tol
+    # The float32 mode's error is the rounding of O(1) float32 intermediates (6e-8 absolute), whatever the size of the
+    # result: its assertions are absolute below |ref| = 1 (floor 1.0) and say so; REF is relative down to 1e-3.
+    tol, fl = (RTOL, 1e-3) if precision == "ref" else (1e-4, 1.0)
+    assert rel_err(obs[ok], nxt[ok], floor=fl) <= tol
+    assert rel_err(rew[ok], gr[ok], floor=fl) <= tol
     near = ok & (np.abs(s0[:, 2]) < 15.0) & (np.abs(s0[:, 3]) < 20.0)
-    assert rel_err(obs[near], nxt[near]) <= RTOL
+    assert rel_err(obs[near], nxt[near], floor=fl) <= RTOL
     # masks: bit-exact wherever the float32/float64 observation is not within tolerance of a threshold
     thr = 5.0 if name == "swingup" else 2.4
     margin = np.abs(np.abs(nxt[:, 0]) - thr) < 1e-4
@@ -174,33 +176,34 @@ def test_freeze_unfreeze_restores_state():
 
 @pytest.mark.parametrize("name", ["swingup", "balancing"])
 def test_stateless_batch_functions_vs_golden(cartpole_golden, name):
+    """get_batch_reward / get_batch_terminal / get_batch_next_obs on the reference's own float64 rows, EVERY golden row:
+    the *_io entry points take float64 observations unnarrowed (cartpole.py:124-129,145-151 compute on float64 arrays),
+    so no row needs a mask: rewards 1e-5, terminal bits equal — including |theta| ~ 600 rad, x within 1e-7 of a
+    threshold, NaN and inf rows."""
     from emei_amd import engine as E
 
     g = cartpole_golden
     obs = g[f"batch_{name}_obs"]
-    o32 = torch.as_tensor(obs, dtype=torch.float32, device="cuda")
-    rew = E.batch_reward(ENV[name], o32).cpu().numpy()
-    term = E.batch_terminal(ENV[name], o32).cpu().numpy()
-    # the function's argument is float32(obs): against the oracle on exactly that argument the result
-    # is float32-exact; against the golden float64 rows it is 1e-5 wherever float32(theta) resolves theta
+    o64 = torch.as_tensor(obs, dtype=torch.float64, device="cuda")
+    rew, term = E.batch_reward(ENV[name], o64), E.batch_terminal(ENV[name], o64)
+    assert rew.dtype == torch.float64
+    assert rel_err(rew.cpu().numpy(), g[f"batch_{name}_reward"][:, 0]) <= RTOL
+    assert np.array_equal(term.cpu().numpy(), g[f"batch_{name}_terminal"][:, 0])
+    # float32 rows (the round-1 entry points): exact for the float32 argument they are given
     from oracle import oracle as O
 
-    o64 = o32.double().cpu().numpy()
-    assert rel_err(rew, O.cartpole_reward(name, o64)) <= 2e-7
-    near = np.abs(obs[:, 2]) < 15.0
-    assert rel_err(rew[near], g[f"batch_{name}_reward"][near, 0]) <= RTOL
-    assert np.array_equal(term, O.cartpole_terminal(name, o64))
-    away = np.abs(np.abs(obs[:, 0]) - (5.0 if name == "swingup" else 2.4)) > 1e-5
-    if name == "balancing":
-        away &= np.abs(np.abs(obs[:, 2]) - 12 * 2 * np.pi / 360) > 1e-6
-    assert np.array_equal(term[away], g[f"batch_{name}_terminal"][away, 0])
-    # get_batch_next_obs: one step from observations == golden one-step next state
+    o32 = torch.as_tensor(obs, dtype=torch.float32, device="cuda")
+    a32 = o32.double().cpu().numpy()
+    r32 = E.batch_reward(ENV[name], o32)
+    assert r32.dtype == torch.float32 and rel_err(r32.cpu().numpy(), O.cartpole_reward(name, a32)) <= 2e-7
+    assert np.array_equal(E.batch_terminal(ENV[name], o32).cpu().numpy(), O.cartpole_terminal(name, a32))
+    # get_batch_next_obs: one step from float64 observations == golden one-step next state, every row the reference computed
     s0, act = g[f"onestep_{name}_state"], g[f"onestep_{name}_action"]
     ok = ~g[f"onestep_{name}_fr4_dt0.02_raised"]
-    nxt = E.batch_next_obs(ENV[name], torch.as_tensor(s0, dtype=torch.float32, device="cuda"),
-                           torch.as_tensor(act, device="cuda"), 0.02, 4, "ref").cpu().numpy()
-    near = ok & (np.abs(s0[:, 2]) < 15.0) & (np.abs(s0[:, 3]) < 20.0)  # float32 inputs: see one-step test
-    assert rel_err(nxt[near], g[f"onestep_{name}_fr4_dt0.02_next"][near]) <= RTOL
+    nxt = E.batch_next_obs(ENV[name], torch.as_tensor(s0, dtype=torch.float64, device="cuda"),
+                           torch.as_tensor(act, device="cuda"), 0.02, 4, "ref")
+    assert nxt.dtype == torch.float64
+    assert rel_err(nxt.cpu().numpy()[ok], g[f"onestep_{name}_fr4_dt0.02_next"][ok]) <= RTOL
 
 
 def test_bad_arguments_raise():

@@ -87,12 +87,20 @@ def test_reference_behaviour_and_env_api(mujoco_golden):
     assert obs.shape == (18,) and not terminal and np.isfinite(reward)
     g = mujoco_golden
     o, po, ac = g["cheetah_obs"], g["cheetah_pre_obs"], g["cheetah_action"]
-    r = env.get_batch_reward(np.nan_to_num(o), po, ac)
-    want = g["cheetah_reward_B1"]
-    okr = np.isfinite(o[:, 0])
-    assert rel_err(r[okr, 0], want[okr]) <= 2e-4  # float32 x-differences divided by dt_env = 0.008
-    t = E.batch_terminal("HalfCheetahRunning", torch.as_tensor(o, dtype=torch.float32, device="cuda")).cpu().numpy()
-    assert np.array_equal(t, g["cheetah_terminal"][:, 0])
+    r = env.get_batch_reward(o, po, ac)  # float64 rows in, float64 arithmetic on them (half_cheetah.py:59-63)
+    assert r.dtype == np.float64 and rel_err(r[:, 0], g["cheetah_reward_B1"]) <= 1e-5  # every row (NaN rows: NaN on both sides)
+    t = env.get_batch_terminal(o)
+    assert np.array_equal(t, g["cheetah_terminal"])
+    # what the reference EXECUTES for B > 1: np.sum(np.square(action)) has no axis, the control cost of the whole batch is
+    # charged to every row (half_cheetah.py:61) — opt-in, per call or per env
+    rq = env.get_batch_reward(o, po, ac, reference_batch_semantics=True)
+    assert rel_err(rq, g["cheetah_reward_batchquirk"]) <= 1e-5
+    env.reference_batch_semantics = True
+    assert np.array_equal(env.get_batch_reward(o, po, ac), rq)
+    assert rel_err(env.get_batch_reward(o[:1], po[:1], ac[:1])[:, 0], g["cheetah_reward_B1"][:1]) <= 1e-5  # B = 1: the same thing
+    env.reference_batch_semantics = False
+    t32 = E.batch_terminal("HalfCheetahRunning", torch.as_tensor(o, dtype=torch.float32, device="cuda")).cpu().numpy()
+    assert np.array_equal(t32, g["cheetah_terminal"][:, 0])
 
 
 def test_full_size_config4_properties():

@@ -36,7 +36,9 @@ def test_cartpole_dataset_rows_are_transitions(tmp_path):
     # (3) every row is one reference step: (obs, a) -> next_obs, reward, done (oracle on the float32 observation)
     rows = np.random.default_rng(0).choice(N * T, 2048, replace=False)
     o_nxt, o_rew, o_term = O.cartpole_step("balancing", d["observations"][rows].astype(np.float64), d["actions"][rows, 0].astype(np.int32))
-    assert rel_err(d["next_observations"][rows], o_nxt) <= 1e-5
+    # the oracle restarts from the float32 observation the dataset stores, the kernel stepped from its float64 state: the input
+    # itself differs by float32 rounding of O(1) coordinates (6e-8 absolute), which every output coordinate inherits
+    assert rel_err(d["next_observations"][rows], o_nxt, floor=1.0) <= 1e-5
     assert rel_err(d["rewards"][rows], o_rew) <= 1e-5
     clear = (np.abs(np.abs(o_nxt[:, 0]) - 2.4) > 1e-5) & (np.abs(np.abs(o_nxt[:, 2]) - 12 * 2 * np.pi / 360) > 1e-6)
     tm = d["timeouts"][rows] != 0

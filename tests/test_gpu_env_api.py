@@ -78,8 +78,8 @@ def test_vectorised_env_and_batch_functions(cartpole_golden):
     ob = g["batch_swingup_obs"]
     r_np, t_np = env.get_batch_reward(ob), env.get_batch_terminal(ob)
     assert r_np.shape == (len(ob), 1) and r_np.dtype == np.float64 and t_np.dtype == np.bool_
-    near = np.abs(ob[:, 2]) < 15.0  # the ABI takes float32 observations: |theta| ~ 600 rad rows lose 3e-5 rad
-    assert rel_err(r_np[near], g["batch_swingup_reward"][near]) <= 1e-5
+    assert rel_err(r_np, g["batch_swingup_reward"]) <= 1e-5  # every row: float64 NumPy rows reach the kernel unnarrowed
+    assert np.array_equal(t_np, g["batch_swingup_terminal"])
     assert isinstance(env.get_batch_reward(torch.as_tensor(ob, device=obs.device)), torch.Tensor)
     assert np.array_equal(emei_amd.CartPoleBalancingEnv().get_batch_reward(ob), np.ones((len(ob), 1)))
     # get_batch_next_obs needs a frozen env (core.py:190-193) and leaves the env's own state alone

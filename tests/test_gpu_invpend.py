@@ -48,9 +48,10 @@ def test_onestep_vs_oracle(variant, fr, dt, precision):
     eng.set_state(s0)
     obs, rew, done = eng.step(torch.as_tensor(act, device=eng.device))
     o_st, o_obs, o_rew, o_term = O.ip_step(variant, s0, act.astype(np.float64), fr, dt)
-    tol = RTOL if precision == "ref" else 2e-4
-    assert rel_err(obs.cpu().numpy(), o_obs) <= tol
-    assert rel_err(rew.cpu().numpy(), o_rew) <= tol
+    # float32 mode: O(1) float32 intermediates (stiff rail force x dt) set an ABSOLUTE error, stated as such (floor 1.0)
+    tol, fl = (RTOL, 1e-3) if precision == "ref" else (2e-4, 1.0)
+    assert rel_err(obs.cpu().numpy(), o_obs, floor=fl) <= tol
+    assert rel_err(rew.cpu().numpy(), o_rew, floor=fl) <= tol
     if precision == "ref":
         assert rel_err(eng.get_state().cpu().numpy(), o_st, floor=1e-30) <= 1e-9
         assert rel_err(eng.get_obs().cpu().numpy(), o_obs, floor=1e-30) <= 1e-9
@@ -94,13 +95,11 @@ def test_reward_terminal_vs_golden(mujoco_golden, variant):
 
     g = mujoco_golden
     obs = g["ip_obs"]
-    o32 = torch.as_tensor(obs, dtype=torch.float32, device="cuda")
-    rew = E.batch_reward(VARIANTS[variant], o32).cpu().numpy()
-    term = E.batch_terminal(VARIANTS[variant], o32).cpu().numpy()
+    o64 = torch.as_tensor(obs, dtype=torch.float64, device="cuda")  # float64 rows, as the reference computes (inverted_pendulum.py:73-183)
+    rew = E.batch_reward(VARIANTS[variant], o64).cpu().numpy()
+    term = E.batch_terminal(VARIANTS[variant], o64).cpu().numpy()
     assert rel_err(rew, g[f"ip_{variant}_reward"][:, 0]) <= RTOL
-    y = np.cos(obs[:, 1])
-    clear = (np.abs(y - 0.9) > 1e-6) & (np.abs(y) > 1e-6) & (np.abs(np.abs(obs[:, 0]) - 2) > 1e-6)
-    assert np.array_equal(term[clear], g[f"ip_{variant}_terminal"][clear, 0])
+    assert np.array_equal(term, g[f"ip_{variant}_terminal"][:, 0])  # every golden row, bit for bit
 
 
 def test_behaviour_like_reference_tests():

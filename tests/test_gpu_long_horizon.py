@@ -1,0 +1,60 @@
+"""The contact bodies over the horizon the reference's callers live in (zoo/util.py:54-73 loops to max_episode_steps = 1000,
+register_env.py:87-91): 4096 envs x 1000 steps from the device reset, Hopper RK4 (fr 4, dt 0.002: hopper.py:17-22) and
+HalfCheetah Euler (half_cheetah.py:16-21), both constraint solvers, the oracle re-synchronised every 20 steps over the
+WHOLE horizon.  From step ~80 on the bodies lie on the ground with a dozen active constraint rows each — the regime the
+60-step tests of test_gpu_hopper.py / test_gpu_cheetah.py never reach (the round-2 statistics build
+of exactly this Hopper kernel was miscompiled; the shipped one is what this test pins).
+
+Parity with libmujoco stays unpinned: this is kernel <-> oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N, T, SEG = 4096, 1000, 20
+
+
+def _scaled(a, b):
+    with np.errstate(all="ignore"):
+        d = np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+    return np.where(np.isnan(d), np.inf, d)
+
+
+@pytest.mark.parametrize("env,integ,body,na,sigma", [("HopperRunning", "rk4", "hopper", 3, 5e-3),
+                                                      ("HalfCheetahRunning", "euler", "cheetah", 6, 0.1)])
+@pytest.mark.parametrize("solver", ["newton", "sweep1"])
+def test_thousand_steps_against_the_resynchronised_oracle(env, integ, body, na, sigma, solver):
+    from emei_amd import _lib as L
+    from emei_amd.engine import Engine
+    from oracle import oracle as O
+
+    step = O.hopper_step if body == "hopper" else O.cheetah_step
+    rng = np.random.default_rng(11)
+    acts = rng.uniform(-1, 1, (T, N, na)).astype(np.float32)
+    eng = Engine(env, N, freq_rate=4, real_time_scale=0.002, integrator=integ, solver=solver, init_noise=sigma, seed=7)
+    eng.reset(7)
+    dev = torch.as_tensor(acts, device=eng.device)
+    rows_late = []
+    for t0 in range(0, T, SEG):
+        st = eng.get_state().cpu().numpy()
+        obs, rew, done = eng.rollout(dev[t0:t0 + SEG].contiguous())
+        assert eng.last_kernel() == (L.KERNEL_BODY_RK4 if integ == "rk4" else L.KERNEL_BODY)
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        assert np.isfinite(obs).all() and np.isfinite(rew).all(), t0
+        assert not done.any()  # never terminal (hopper.py:104-106; finite cheetah), no TimeLimit on this handle
+        ost = st
+        for t in range(SEG):
+            ost, orew, _ = step(ost, acts[t0 + t].astype(np.float64), 4, 0.002, O.opts(integ, solver=solver))
+            assert _scaled(obs[t], ost).max() <= 1e-5, (t0 + t, int(_scaled(obs[t], ost).max(axis=1).argmax()))
+            assert _scaled(rew[t], orew).max() <= 1e-4, t0 + t  # x-difference of float64 states / dt_env = 0.008 in float32 out
+        end = eng.get_state().cpu().numpy()
+        assert np.isfinite(end).all()
+        assert _scaled(end, ost).max() <= 1e-6, t0  # float64 state after a 20-step segment (chaotic contacts amplify the last bits)
+        # per-segment share of lanes with constraint rows: the oracle's row builder on both end states
+        fk, fo = (O.planar_count_rows(body, end) > 0).mean(), (O.planar_count_rows(body, ost) > 0).mean()
+        assert abs(fk - fo) <= 0.05, (t0, fk, fo)
+        if t0 >= 300:
+            rows_late.append(fo)
+    # the regime itself: most lanes are in contact late in the episode (round 2's broken statistics build saw 2 %)
+    assert min(rows_late) > 0.6, min(rows_late)

@@ -14,6 +14,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -148,32 +149,10 @@ def test_no_instruction_touches_an_lds_read_destination_before_its_wait(function
 # ------------------------------------------------------------------------------------------------
 # hipcc bug found in round 2 (DESIGN.md §6, "the cheetah RK4 miscompile"): the register allocator may place VGPR
 # spill stores (v_accvgpr_write_b32 / scratch_store) at the top of a control-flow JOIN block, in front of the
-# `s_or_b64 exec, exec, s[..]` that restores EXEC.  When the skipped branch was empty the wave falls into the block with
-# EXEC = 0, the EXEC-masked spill stores write nothing, and the later reload reads stale registers.
-def exec_restore_hazards(ins):
-    """[(addr of the restore, [vector instructions in front of it])] for the shape
-           s_and_saveexec_b64 sX, cond ; s_cbranch_execnz COLD        (falls through with EXEC = 0 when no lane is in COLD)
-       JOIN:  <vector instructions>                                    <- execute with EXEC = 0 / COLD's lanes only
-              s_or_b64 exec, exec, sX"""
-    out = []
-    for k, (a, m, o) in enumerate(ins):
-        if not (m == "s_or_b64" and re.match(r"exec, exec, s\[\d+:\d+\]", o)):
-            continue
-        saved = o.split(",")[2].strip()
-        j, vec = k - 1, []
-        while j >= 0 and not ins[j][1].startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")) and "exec" not in ins[j][2].split(",")[0]:
-            if ins[j][1].startswith(("v_", "ds_", "global_", "scratch_", "buffer_", "flat_")) and ins[j][1] not in (
-                    "v_readlane_b32", "v_writelane_b32"):  # SGPR spill traffic ignores EXEC
-                vec.append((hex(ins[j][0]), ins[j][1], ins[j][2]))
-            j -= 1
-        if not vec or j < 1 or ins[j][1] != "s_cbranch_execnz":
-            continue
-        # the branch is fed by the saveexec that produced the mask this restore consumes
-        for q in range(j - 1, max(j - 4, -1), -1):
-            if ins[q][1] == "s_and_saveexec_b64" and ins[q][2].split(",")[0].strip() == saved:
-                out.append((hex(a), vec[::-1]))
-                break
-    return out
+# `s_or_b64 exec, exec, s[..]` that restores EXEC: tools/isa_scan.py (shared with tools/build_variant.sh, which audits every
+# variant build the same way — round 2 took its Hopper RK4 solver statistics from a variant that this bug had broken).
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from isa_scan import exec_restore_hazards  # noqa: E402
 
 
 def test_no_vector_instruction_in_front_of_an_exec_restore(functions):
@@ -184,6 +163,54 @@ def test_no_vector_instruction_in_front_of_an_exec_restore(functions):
         if h:
             bad[name] = h[:3]
     assert not bad, bad
+
+
+def _listing(text):
+    """'0x10 mnemonic operands' lines -> [(addr, mnemonic, operands)]"""
+    out = []
+    for line in text.strip().splitlines():
+        a, m, *o = line.split(None, 2)
+        out.append((int(a, 16), m, o[0] if o else ""))
+    return out
+
+
+def test_scanner_flags_both_observed_shapes_and_not_a_plain_then_block():
+    """The two miscompiles seen so far, cut down from the real listings (profiles/r02_rk4_rolled_isa_excerpt.s,
+    profiles/r03_hopper_rk4_stats_isa_excerpt.s), and two shapes that are fine."""
+    shape_a = _listing("""
+        0x100 s_and_saveexec_b64 s[38:39], s[0:1]
+        0x104 s_cbranch_execnz 100
+        0x108 v_accvgpr_write_b32 a117, v83
+        0x110 v_accvgpr_write_b32 a88, v76
+        0x118 s_or_b64 exec, exec, s[38:39]
+        0x11c v_accvgpr_read_b32 v76, a88
+    """)
+    assert len(exec_restore_hazards(shape_a)) == 1
+    shape_b = _listing("""
+        0x6014 s_and_saveexec_b64 s[36:37], s[0:1]
+        0x6018 s_cbranch_execz 3
+        0x601c v_mov_b32_e32 v120, s0
+        0x6020 s_nop 0
+        0x6024 global_atomic_add_x2 v121, v[120:121], s[0:1]
+        0x6028 v_accvgpr_write_b32 a138, v168
+        0x6030 v_accvgpr_write_b32 a136, v156
+        0x6038 s_or_b64 exec, exec, s[36:37]
+        0x603c v_accvgpr_read_b32 v168, a138
+    """)
+    h = exec_restore_hazards(shape_b)
+    assert len(h) == 1 and len(h[0][1]) == 2
+    # the same join, but the slots also have an unmasked store elsewhere: hipcc re-storing a value the slot already holds
+    restore = _listing("0x5000 v_accvgpr_write_b32 a138, v168\n0x5008 v_accvgpr_write_b32 a136, v156") + shape_b
+    notes = []
+    assert exec_restore_hazards(restore, notes) == [] and len(notes) == 1
+    # an ordinary `then` block that falls into its own join: vector work, no spill store behind the label
+    plain = _listing("""
+        0x10 s_and_saveexec_b64 s[2:3], vcc
+        0x14 s_cbranch_execz 2
+        0x18 v_add_f64 v[0:1], v[0:1], v[2:3]
+        0x20 s_or_b64 exec, exec, s[2:3]
+    """)
+    assert exec_restore_hazards(plain) == []
 
 
 def test_every_kernel_fits_the_cu(tmp_path):
