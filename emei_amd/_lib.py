@@ -89,6 +89,7 @@ SYMBOLS = {
     "emei_env_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emei_reset": (C.c_int, [_vp, _u64, _vp]),
     "emei_set_seed": (C.c_int, [_vp, _u64]),
+    "emei_get_solver_cap_hits": (C.c_int, [_vp, _vp, _vp]),
     "emei_last_rollout_kernel": (C.c_int, [_vp]),
     "emei_set_state": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "emei_get_state": (C.c_int, [_vp, _vp, _vp]),

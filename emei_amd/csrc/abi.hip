@@ -28,6 +28,8 @@ struct emei_env {
     void* frozen_state;
     int32_t* frozen_steps;
     uint32_t* frozen_episode;
+    uint64_t frozen_seed;          // key of the reset generator at emei_freeze (restored by emei_unfreeze)
+    unsigned long long* cap_hits;  // device counter: Newton solves that ended at the iteration cap (emei_get_solver_cap_hits)
     bool has_state, frozen;
     int last_kernel;  // enum emei_kernel_id of the last emei_step / emei_rollout
     PendParams pend;
@@ -232,6 +234,8 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (e == hipSuccess) e = hipMalloc(&h->frozen_state, state_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&h->frozen_steps, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&h->frozen_episode, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cap_hits, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->cap_hits, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->done_mask, 0, n_words * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->steps, 0, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(h->episode, 0, n * sizeof(uint32_t));
@@ -259,6 +263,7 @@ extern "C" EMEI_API int emei_destroy(emei_env* h) {
     (void)hipFree(h->frozen_state);
     (void)hipFree(h->frozen_steps);
     (void)hipFree(h->frozen_episode);
+    (void)hipFree(h->cap_hits);
     delete h;
     return EMEI_OK;
 }
@@ -318,6 +323,7 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     L.env_params.mask = h->cfg.env_param_mask;
     memcpy(L.env_params.v, h->cfg.env_params, sizeof(L.env_params.v));
     L.trig = h->trig;
+    L.cap_hits = h->cap_hits;
     L.stream = (hipStream_t)stream;
     return L;
 }
@@ -400,6 +406,7 @@ extern "C" EMEI_API int emei_freeze(emei_env* h, void* stream) {
     HIP_TRY(hipMemcpyAsync(h->frozen_state, h->state, n * h->state_dim * h->real_size, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->frozen_steps, h->steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->frozen_episode, h->episode, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    h->frozen_seed = h->cfg.seed;  // a reset(seed=) between freeze and unfreeze must not re-key the restored episodes
     h->frozen = true;
     return EMEI_OK;
 }
@@ -413,7 +420,15 @@ extern "C" EMEI_API int emei_unfreeze(emei_env* h, void* stream) {
     HIP_TRY(hipMemcpyAsync(h->state, h->frozen_state, n * h->state_dim * h->real_size, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->steps, h->frozen_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->episode, h->frozen_episode, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    h->cfg.seed = h->frozen_seed;
     h->frozen = false;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_get_solver_cap_hits(emei_env* h, uint64_t* count_out, void* stream) {
+    if (!h || !count_out) return fail(EMEI_ERR_INVALID, "emei_get_solver_cap_hits: null argument");
+    EMEI_ON_DEVICE(h, "emei_get_solver_cap_hits");
+    HIP_TRY(hipMemcpyAsync(count_out, h->cap_hits, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return EMEI_OK;
 }
 

@@ -186,6 +186,7 @@ struct BodyLaunch {
     NoiseSpec noise;
     EnvParams env_params;
     const void* trig = nullptr;
+    unsigned long long* cap_hits = nullptr;  // device counter of the handle
     hipStream_t stream = nullptr;
     int* selected = nullptr;  // out: enum emei_kernel_id of the rollout kernel launched
 };
@@ -208,6 +209,7 @@ struct BodyArgs {
     int32_t semi;  // EMEI_INTEG_SEMI_IMPLICIT
     NoiseArgs<Body::NS> noise;
     const SinCosEntry* trig;  // 256-entry {sin,cos} table of this device (abi.hip:emei_trig_table)
+    unsigned long long* cap_hits;  // handle counter (emei_device.h:report_cap_hit)
     typename Body::Model m;
 };
 
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Bod
     trig.tab = trig_s;
     __shared__ R scratch_s[(Body::kScratchPerLane > 0 ? Body::kScratchPerLane : 1) * (Body::kScratchPerLane > 0 ? kBlock : 1)];
     if constexpr (Body::kScratchPerLane > 0) trig.scratch = scratch_s;
+    trig.cap_hits = a.cap_hits;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t n = a.n;
@@ -510,6 +513,7 @@ static int launch_body(const BodyLaunch& L) {
             a.flags = L.flags, a.seed = L.seed, a.env_offset = L.env_offset, a.m = m;
             a.semi = L.integrator == EMEI_INTEG_SEMI_IMPLICIT, a.noise = NoiseArgs<Body::NS>(L.noise);
             a.trig = (const SinCosEntry*)L.trig;
+            a.cap_hits = L.cap_hits;
             if (L.integrator == EMEI_INTEG_RK4)
                 hipLaunchKernelGGL((body_rollout_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, a);
             else

@@ -725,6 +725,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
 
         [[maybe_unused]] int n_pass = 0;
+        bool converged = false;  // the stopping rule was met (otherwise the loop ran into kMaxNewton: report_cap_hit)
         if (dual) {
             // ---- The same iteration in constraint space.  With M = L D L' and, per contact point p, Y_p = L^-1 (J_n, J_t)':
             //   a = a0 - L^-T D^-1 sum_p Y_p g_p,   g_p = W_p (u_p + b_p),   u_q = J_q a = u0_q - sum_p G_qp g_p,   G_qp = Y_q' D^-1 Y_p
@@ -865,7 +866,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 const bool p0 = xn0 + xt0 < R(0), m0 = xn0 - xt0 < R(0), y0 = xn0 < R(0);
                 const bool p1 = xn1 + xt1 < R(0), m1 = xn1 - xt1 < R(0), y1 = xn1 < R(0);
                 const uint32_t flags = (p0 ? 1u : 0u) | (m0 ? 2u : 0u) | (y0 ? 4u : 0u) | (p1 ? 8u : 0u) | (m1 ? 16u : 0u) | (y1 ? 32u : 0u);
-                if (flags == used) break;  // the set the iterate was computed with reproduces itself: the minimiser
+                if (flags == used) {  // the set the iterate was computed with reproduces itself: the minimiser
+                    converged = true;
+                    break;
+                }
                 used = flags;
                 const R c10 = p0 ? R(1) : R(0), c20 = m0 ? R(1) : R(0), cy0 = y0 ? R(2) : R(0);
                 const R c11 = p1 ? R(1) : R(0), c21 = m1 ? R(1) : R(0), cy1 = y1 ? R(2) : R(0);
@@ -1039,7 +1043,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
-            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) break;
+            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) {
+                converged = true;
+                break;
+            }
             EMEI_MARK(nw_step);
             ldl_factor(A, invd);
             ldl_forward<0, true>(A, gr);
@@ -1052,6 +1059,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         }  // primal loop / dual path
         EMEI_MARK(nw_final);
         EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
+        report_cap_hit(trig, !converged);
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;

@@ -152,7 +152,19 @@ struct TrigCtx {
     // per-block LDS scratch of the body kernels (Body::kScratchPerLane elements of Body::real per lane, lane-interleaved:
     // element e of this lane at scratch[e * kBlock + threadIdx.x]); null where a kernel provides none
     void* scratch = nullptr;
+    // handle counter of Newton solves that ended at the iteration cap without meeting their stopping rule (emei_get_solver_cap_hits);
+    // null in the stateless kernels
+    unsigned long long* cap_hits = nullptr;
 };
+// The unit-step Newton iteration of the multi-constraint bodies has no line search (cheetah_model.h:accel_newton): it is the
+// active-set iteration of a strictly convex piecewise-quadratic cost and ends in a handful of passes, but nothing PROVES it
+// cannot cycle.  A lane that reaches the cap is therefore COUNTED: the parity tests assert the counter stays 0.
+// Wave-uniform entry, the lanes add 0 / 1: no divergent branch in the hot kernel.
+__device__ __forceinline__ void report_cap_hit(const TrigCtx& t, bool hit) {
+    if (__builtin_expect(__ballot(hit) != 0ull, 0)) {
+        if (t.cap_hits) atomicAdd(t.cap_hits, hit ? 1ull : 0ull);
+    }
+}
 __device__ __forceinline__ void trig_ctx_init(TrigCtx& t, const SinCosEntry* tab) {
     t.tab = tab;
     t.c3 = -1.0 / 6, t.c4 = 1.0 / 24;

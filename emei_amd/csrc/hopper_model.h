@@ -494,6 +494,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) fmax = fmax > fabs(f[i]) ? fmax : fabs(f[i]);
         [[maybe_unused]] int n_pass = 0;
+        bool converged = false;  // see cheetah_model.h
 #pragma unroll 1
         for (int it = 0; it < cheetah::kMaxNewton; ++it) {
             R gr[NV];
@@ -581,7 +582,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
-            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) break;  // per lane, as in cheetah_model.h
+            if (gmax <= R(sizeof(R) == 8 ? 1e-11 : 1e-5) * fmax) {  // per lane, as in cheetah_model.h
+                converged = true;
+                break;
+            }
             ldl_factor(A, invd);
             ldl_forward<0>(A, gr);
 #pragma unroll
@@ -591,6 +595,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
         }
         EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
+        report_cap_hit(trig, !converged);
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;

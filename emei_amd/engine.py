@@ -95,6 +95,7 @@ class Engine:
                            *((lambda m, a: (m, L.SOLVERS[solver], a))(*L.pack_env_params(env_params))))
         self._h = C.c_void_p()
         self._host_io = None
+        self._out_ok = {}  # validated `out=` tuples by identity (_check_outputs)
         with torch.cuda.device(self.device):
             L.check(L.lib().emei_create(C.byref(cfg), C.byref(self._h)))
 
@@ -117,6 +118,13 @@ class Engine:
     def set_seed(self, seed):
         """Re-key the device reset generator (auto-reset episodes) without touching the state."""
         L.check(L.lib().emei_set_seed(self._h, int(seed) & (2**64 - 1)))
+
+    @_on_device
+    def solver_cap_hits(self):
+        """Newton solves of this engine's rollouts that ended at the iteration cap without converging (must stay 0)."""
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        L.check(L.lib().emei_get_solver_cap_hits(self._h, _ptr(out), _stream()))
+        return int(out.item())
 
     def last_kernel(self):
         """enum emei_kernel_id of the kernel the last step / rollout launched (_lib.KERNEL_NAMES)."""
@@ -164,11 +172,34 @@ class Engine:
             raise ValueError("actions must be contiguous")
         return _ACT_DTYPES[actions.dtype]
 
+    def _check_outputs(self, out, lead):
+        """Caller-supplied output buffers go to the ABI as raw pointers (it has no size arguments): a wrong shape, dtype,
+        device or stride would be a silent out-of-bounds device write.  Checked once per distinct `out` tuple object (the
+        per-step path pays one dictionary lookup; tensors are immutable in shape / dtype / device)."""
+        hit = self._out_ok.get(id(out))
+        if hit is not None and hit[0] is out and hit[1] == lead:
+            return out
+        if not isinstance(out, (tuple, list)) or len(out) != 3:
+            raise ValueError("out must be (obs, reward, done)")
+        want = ((lead + (self.n_envs, self.obs_dim), torch.float32, "obs"), (lead + (self.n_envs,), torch.float32, "reward"),
+                (lead + (self.n_envs,), torch.uint8, "done"))
+        for t, (shape, dtype, name) in zip(out, want):
+            if not isinstance(t, torch.Tensor) or t.device != self.device:
+                raise ValueError(f"out: {name} must be a tensor on {self.device}")
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError(f"out: {name} is {tuple(t.shape)} {t.dtype}, expected {shape} {dtype}")
+            if not t.is_contiguous():
+                raise ValueError(f"out: {name} must be contiguous")
+        if len(self._out_ok) >= 4096:
+            self._out_ok.clear()
+        self._out_ok[id(out)] = (out, lead)  # holding the tuple keeps its id (and the tensors' shapes) valid
+        return out
+
     @_on_device
     def step(self, actions, auto_reset=False, out=None):
         """-> obs [N,obs_dim] f32, reward [N] f32, done [N] u8 (bit0 terminal, bit1 truncated)."""
         dt = self._check_actions(actions, ())
-        obs, rew, done = out if out is not None else self.alloc_outputs(None)
+        obs, rew, done = self._check_outputs(out, ()) if out is not None else self.alloc_outputs(None)
         L.check(L.lib().emei_step(self._h, _ptr(actions), dt, _ptr(obs), _ptr(rew), _ptr(done),
                                   L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
@@ -203,7 +234,7 @@ class Engine:
         """actions [T,N(,act_dim)] -> obs [T,N,obs_dim] f32, reward [T,N] f32, done [T,N] u8; one launch."""
         T = int(actions.shape[0])
         dt = self._check_actions(actions, (T,))
-        obs, rew, done = out if out is not None else self.alloc_outputs(T)
+        obs, rew, done = self._check_outputs(out, (T,)) if out is not None else self.alloc_outputs(T)
         L.check(L.lib().emei_rollout(self._h, T, _ptr(actions), dt, _ptr(obs), _ptr(rew), _ptr(done),
                                      L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done

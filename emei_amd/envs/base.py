@@ -168,11 +168,13 @@ class HipEnv(EmeiEnv):
 
     # -- freeze / unfreeze: device-to-device snapshot of the state SoA -------------------------------
     def freeze(self) -> None:
-        self.engine.freeze()
+        self.engine.freeze()  # state, counters and the device reset key (emei_freeze)
+        self._frozen_seed = (self._dev_seed_base, self._dev_seed_count)  # ... and the host side of that key
         self.frozen = True
 
     def unfreeze(self) -> None:
         self.engine.unfreeze()
+        self._dev_seed_base, self._dev_seed_count = self._frozen_seed
         self.frozen = False
 
     # -- batched functions of the EmeiEnv surface ------------------------------------------------------

@@ -25,7 +25,7 @@ extern "C" {
 /* ABI history.  1: emei_config of 64 B.  2: integrator / noise layout / per-coordinate sigmas (328 B), env_params (400 B),
  * emei_set_seed, emei_last_rollout_kernel, emei_config.solver (the former reserved0; reserved words MUST be zero).
  * 3: the *_io stateless entry points (float64 observations), emei_freeze / emei_unfreeze snapshot the reset key,
- *    emei_model_constants, emei_solver_cap_hits. */
+ *    emei_model_constants, emei_get_solver_cap_hits. */
 #define EMEI_ABI_VERSION 3
 
 #if defined(__GNUC__)
@@ -191,9 +191,16 @@ EMEI_API int emei_get_state(emei_env* h, double* state_aos, void* stream);
 EMEI_API int emei_get_obs(emei_env* h, double* obs_aos, void* stream);
 
 /* Freezable.freeze / unfreeze (base_control.py:32-36; mujoco_env.py:114-120): device-to-device
- * snapshot / restore of the state SoA and counters. */
+ * snapshot / restore of the state SoA, the counters and the key of the reset generator (so that the auto-reset episodes of
+ * the restored trajectory draw what they would have drawn, whatever reset(seed=) happened in between). */
 EMEI_API int emei_freeze(emei_env* h, void* stream);
 EMEI_API int emei_unfreeze(emei_env* h, void* stream);
+
+/* Newton solves of this handle's HalfCheetah / Hopper rollouts that ended at the iteration cap (24 passes) WITHOUT meeting their
+ * stopping rule, since emei_create: count_out [1] uint64 (device-accessible).  The kernels' iteration takes unit Newton steps
+ * without a line search; it has never been seen to need more than 9 passes, and this counter is how that is checked
+ * (tests/test_gpu_parity_sweeps.py, tests/test_gpu_long_horizon.py assert 0).  Always 0 for the other envs and the SWEEP1 solver. */
+EMEI_API int emei_get_solver_cap_hits(emei_env* h, uint64_t* count_out, void* stream);
 
 /* Re-key the device reset generator without touching the state: the seed of Env.reset(seed=) reaches the
  * handle also when the initial state itself is drawn on the host and uploaded with emei_set_state

@@ -30,7 +30,7 @@ for body, name, nv, nu, step in (("cheetah", "HalfCheetahRunning", 9, 6, O.cheet
         err = np.abs(got - want).max(axis=1) / np.maximum(1.0, np.abs(want).max(axis=1))
         bad = int((err > 1e-9).sum())
         print(f"{body} {integ} freq_rate={fr}: {n} states, worst scaled difference {err.max():.2e}, {bad} above 1e-9, "
-              f"non-finite {int((~np.isfinite(got)).any(axis=1).sum())}", flush=True)
+              f"non-finite {int((~np.isfinite(got)).any(axis=1).sum())}, solves at the iteration cap {eng.solver_cap_hits()}", flush=True)
         eng.close()
 
 # the single-constraint body (InvertedDoublePendulum, body_rollout_kernel): states on and beyond the rail and its margin

@@ -125,3 +125,50 @@ def test_reset_seed_reaches_device_generator():
     env.reset()  # un-seeded reset after reset(seed=1): a fresh key, np_random untouched
     env.rollout(acts)
     assert not torch.equal(env.engine.get_obs(), a)
+
+
+def test_output_buffers_are_validated():
+    """Engine.step / rollout(out=...): the ABI takes raw pointers without sizes, so a wrong buffer is refused on the host."""
+    from emei_amd.engine import Engine
+
+    eng = Engine("CartPoleSwingUp", 128)
+    eng.reset(0)
+    a = torch.zeros(128, dtype=torch.uint8, device=eng.device)
+    good = eng.alloc_outputs(None)
+    eng.step(a, out=good)
+    eng.step(a, out=good)  # the validated tuple is remembered
+    assert eng.last_kernel() != 0  # emei_step goes through emei_rollout: the getter covers the step path too
+    obs, rew, done = good
+    for bad in ((obs[:64], rew, done), (obs, rew.double(), done), (obs, rew, done.to(torch.int32)), (obs.cpu(), rew, done),
+                (torch.empty((128, 8), dtype=torch.float32, device=eng.device)[:, ::2], rew, done), (obs, rew), None):
+        if bad is None:
+            continue
+        with pytest.raises(ValueError):
+            eng.step(a, out=bad)
+    acts = torch.zeros((16, 128), dtype=torch.uint8, device=eng.device)
+    with pytest.raises(ValueError):
+        eng.rollout(acts, out=good)  # step-shaped buffers for a 16-step rollout
+    eng.rollout(acts, out=eng.alloc_outputs(16))
+
+
+def test_freeze_reset_unfreeze_keeps_the_auto_reset_episodes():
+    """the key of the device reset generator is part of the frozen snapshot.  freeze -> reset(seed=other) ->
+    unfreeze -> auto-reset rollout must reproduce the rollout of an env that was never re-seeded."""
+    import emei_amd
+
+    acts = torch.as_tensor(np.random.default_rng(5).integers(2, size=(300, 256)), device="cuda")
+
+    def run(reseed):
+        env = emei_amd.CartPoleBalancingEnv(num_envs=256, auto_reset=True, max_episode_steps=500)
+        env.reset(seed=11)
+        env.freeze()
+        if reseed:
+            env.reset(seed=99)
+            env.rollout(acts[:7])
+        env.unfreeze()
+        return env.rollout(acts)
+
+    a, b = run(False), run(True)
+    assert int((a[2] | a[3]).sum()) > 256  # every env went through several auto-resets
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

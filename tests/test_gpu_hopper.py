@@ -120,6 +120,8 @@ def test_reference_tests_and_env_api(hopper_golden):
     assert np.array_equal(env.get_batch_terminal(o), g["hopper_terminal"]) and not g["hopper_terminal"].any()
     t = E.batch_terminal("HopperRunning", torch.as_tensor(np.nan_to_num(o), dtype=torch.float32, device="cuda")).cpu().numpy()
     assert not t.any()
+    # the whole-batch control cost hopper.py:98 executes for B > 1 (np.sum without an axis): opt-in
+    assert rel_err(env.get_batch_reward(o, po, ac, reference_batch_semantics=True), g["hopper_reward_batchquirk"]) <= 1e-5
 
 
 def test_auto_reset_truncation_and_dataset():
