@@ -365,6 +365,16 @@ def xml_constants(model):
     return out[:n].copy()
 
 
+def planar_row_mask(body, state):
+    """Bit mask of the constraint rows present at each state [n, 2 nv]: limits of the actuated joints in the low bits, then two
+    bits per capsule (its end spheres) in XML geom order."""
+    nv = 9 if body == "cheetah" else 6
+    st = np.ascontiguousarray(state, np.float64).reshape(-1, 2 * nv)
+    out = np.empty(len(st), np.uint32)
+    lib().planar_oracle_row_mask(C.c_int(0 if body == "cheetah" else 1), C.c_int64(len(st)), _p(st, C.c_double), _p(out, C.c_uint32))
+    return out
+
+
 def planar_invweights(body):
     """(dof_invweight0 [nv], body_invweight0 [nb]) of the planar-tree oracle at qpos0 (mj_setConst)."""
     nv, nb = (9, 7) if body == "cheetah" else (6, 4)

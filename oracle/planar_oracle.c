@@ -815,6 +815,28 @@ EXPORT void planar_oracle_count_rows(int body, int64_t n, double dt, const doubl
         nrows_out[i] = build_rows(&m, &k, dt, q, q + nv, rows);
     }
 }
+/* diagnostics: which rows exist at each state, as a bit mask — bit (i - 3) for a violated limit of joint dof i, bit
+ * (nv - 3 + 2 g + e) for end sphere e of capsule g inside the contact margin (the kernels' `rows` word has the same meaning) */
+EXPORT void planar_oracle_row_mask(int body, int64_t n, const double* state, uint32_t* mask_out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    const int nv = m.nv;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double* q = state + 2 * nv * i;
+        kin_t k;
+        kinematics(&m, q, &k);
+        uint32_t mask = 0;
+        for (int d = 3; d < nv; ++d)
+            if (m.limited[d] && (q[d] < m.range_lo[d] || q[d] > m.range_hi[d])) mask |= 1u << (d - 3);
+        for (int g = 0; g < m.ng; ++g)
+            for (int e = 0; e < 2; ++e) {
+                v2 sp = add(k.org[m.geom_body[g]], rot(k.phi[m.geom_body[g]], m.geom_end[g][e]));
+                if (sp.z - m.geom_radius[g] < m.contact_margin) mask |= 1u << (nv - 3 + 2 * g + e);
+            }
+        mask_out[i] = mask;
+    }
+}
 EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
     planar_model_t m;
     if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
