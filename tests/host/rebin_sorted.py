@@ -4,7 +4,7 @@ after 300 steps the envs are re-ordered on the host by the row mask of their sta
 violated, which capsule ends touch the floor), so that the waves of the next launch are as homogeneous as the signature
 makes them; the launch of K steps is timed against the same envs in their original order.  K = 1 .. 32 shows how fast the
 homogeneity decays (contacts change), i.e. how often a real implementation would have to re-bin.
-(tools/rebin_bound.py measured the limit: identical lanes per wave.)"""
+(tools/rebin_bound.py measured the limit: identical lanes per wave.)  Lives under tests/host/ because it uses the oracle row builder."""
 import sys
 
 import numpy as np
