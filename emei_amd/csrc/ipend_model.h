@@ -81,6 +81,14 @@ struct InvPendBody {
         const R idet = rcp_r(fma_r(-M12, M12, M11 * M22));
         R a0 = fma_r(M22, f1, -(M12 * f2)) * idet;
         R a1 = fma_r(M11, f2, -(M12 * f1)) * idet;
+        // Balancing variants: slider range AND the hinge's +-90 degree stop, in the general two-row form (pendulum_envs.h:
+        // ip_limit_rows); SwingUp variants (free hinge): the slider's one-row closed form below
+        if constexpr (VARIANT < 2) {
+            constexpr IpModel x = ip_make_model(false);
+            ip_limit_rows(x, q[0], q[1], v[0], v[1], M12, idet, (R)m.K, (R)m.B, a0, a1);
+            qacc[0] = a0, qacc[1] = a1;
+            return;
+        }
         // soft slider limit; x_lo < x_hi: at most one side is violated, the smaller distance is it
         const R dlo = q[0] - (R)m.x_lo, dhi = (R)m.x_hi - q[0];
         const bool lower = dlo < dhi;

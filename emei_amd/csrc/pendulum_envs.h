@@ -176,6 +176,9 @@ struct IpModel {
     // THE one hand-typed copy of inverted_pendulum.xml on the kernel side: ipend_model.h and abi.hip:pend_params read these
     // fields, emei_model_constants exports them, tests/test_model_constants.py pins them to the file.
     double mc, mp, Icom, r, phi0, solref_tc, width;
+    // hinge range (xml:17, +-90 degrees, `limited` by the joint default) and its dof_invweight0: a limit row of the Balancing
+    // variants only (SwingUp's _update_model sets the range to +-inf, inverted_pendulum.py:135-137)
+    double th_lo, th_hi, invw_hinge;
 };
 constexpr IpModel ip_make_model(bool swingup) {
     IpModel m{};
@@ -196,6 +199,8 @@ constexpr IpModel ip_make_model(bool swingup) {
     m.sin_off = ce::sin(m.phi_off), m.cos_off = ce::cos(m.phi_off);
     const double M12 = m.mpr * ce::cos(phi0);
     m.invw = m.M22 / (m.M11 * m.M22 - M12 * M12);  // dof_invweight0 of the slider at qpos0
+    m.invw_hinge = m.M11 / (m.M11 * m.M22 - M12 * M12);
+    m.th_lo = -pi / 2, m.th_hi = pi / 2;
     m.dmin = 0.9, m.dmax = 0.95, m.width = 0.001, m.inv_width = 1.0 / 0.001;  // default solimp (.9 .95 .001)
     m.mc = mc, m.mp = mp, m.Icom = Icom, m.r = r, m.phi0 = phi0, m.solref_tc = 0.02;  // default solref (.02 1)
     return m;
@@ -212,6 +217,46 @@ inline int ip_xml_constants(double* out) {
     return 15;
 }
 
+// Joint-limit rows of the InvertedPendulum in their general form — the slider's range and, for the Balancing variants, the hinge's
+// +-90 degree range — as oracle/emei_oracle.c:ip_accel states them: MuJoCo's primal problem with at most two rows is the 2 x 2
+// complementarity problem f >= 0, (A + R) f - b >= 0, f'((A + R) f - b) = 0 (A = J M^-1 J', b_i = aref_i - J_i a0), solved by
+// enumerating its four active sets (A + R is positive definite: exactly one is consistent).  The hinge stop is only reached by a
+// POST-terminal state (Rebound terminates at cos theta < 0.9, Boundary at cos theta < 0; the reference keeps stepping after
+// `terminal`), so this runs on a cold, wave-uniform path; the hot path keeps the one-row closed form of the slider.
+// M12 = mpr cos(phi), idet = 1 / (M11 M22 - M12^2); a0 / a1 enter as the smooth accelerations and leave constrained.
+template <typename R>
+__device__ __forceinline__ void ip_limit_rows(const IpModel& m, R x, R th, R v0, R v1, R M12, R idet, R limK, R limB, R& a0, R& a1) {
+    R J[2], b[2], Rr[2];
+    auto row = [&](int i, R qi, R vi, R lo, R hi, R invw, R ai) __attribute__((always_inline)) {
+        const bool low = qi < lo, high = qi > hi, on = low | high;
+        const R dist = low ? qi - lo : hi - qi;
+        const R Ji = low ? R(1) : R(-1);
+        const R xx = fabs(dist) * (R)m.inv_width;
+        const R u1 = R(1) - xx;
+        const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
+        const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+        const R aref = fma_r(-limK * imp, dist, -limB * (Ji * vi));
+        J[i] = on ? Ji : R(0);
+        b[i] = on ? aref - Ji * ai : R(0);
+        Rr[i] = on ? div_r(R(1) - imp, imp) * invw : R(1);
+    };
+    row(0, x, v0, (R)m.x_lo, (R)m.x_hi, (R)m.invw, a0);
+    row(1, th, v1, (R)m.th_lo, (R)m.th_hi, (R)m.invw_hinge, a1);
+    const bool has0 = J[0] != R(0), has1 = J[1] != R(0);
+    const R A01 = J[0] * J[1] * (-M12 * idet);
+    const R H00 = fma_r((R)m.M22, idet, Rr[0]), H11 = fma_r((R)m.M11, idet, Rr[1]);
+    const R s0 = div_r(b[0], H00), s1 = div_r(b[1], H11);  // one row alone
+    const R id2 = rcp_r(fma_r(H00, H11, -(A01 * A01)));
+    const R t0 = fma_r(H11, b[0], -(A01 * b[1])) * id2, t1 = fma_r(H00, b[1], -(A01 * b[0])) * id2;  // both rows
+    const bool both = has0 & has1 & (t0 > R(0)) & (t1 > R(0));
+    const bool only0 = !both & has0 & (s0 > R(0)) & !(has1 & (b[1] - A01 * s0 > R(0)));
+    const bool only1 = !both & !only0 & has1 & (s1 > R(0)) & !(has0 & (b[0] - A01 * s1 > R(0)));
+    const R f0 = both ? t0 : (only0 ? s0 : R(0)), f1 = both ? t1 : (only1 ? s1 : R(0));
+    const R g0 = J[0] * f0, g1 = J[1] * f1;  // generalised force J' f, through M^-1
+    a0 = fma_r(fma_r((R)m.M22, g0, -(M12 * g1)), idet, a0);
+    a1 = fma_r(fma_r((R)m.M11, g1, -(M12 * g0)), idet, a1);
+}
+
 template <int VARIANT, typename R>
 struct InvPend {
     using real = R;
@@ -221,7 +266,11 @@ struct InvPend {
     // BASELINE configs[2]: 262 144 envs = 4 waves per SIMD, which only fit with <= 128 registers per lane (and <= 40 KiB
     // of LDS per block): the spare initial state of the reset path goes to LDS, the rollout is compiled for 4 waves
     static constexpr bool kSpareInLds = true;
-    static constexpr int kMinWavesPerEU = 4;
+    // The SwingUp variants (BASELINE configs[2] is BoundarySwingUp) are compiled for 4 waves per SIMD (<= 128 registers).  The
+    // Balancing variants carry the two-row limit solve of the hinge stop (ip_limit_rows, a cold path): under the 128-register
+    // cap it spilled 12-20 B to scratch (scratch traffic shares vmcnt with the staged tile loads: tests/test_isa_guards.py),
+    // so they are compiled for 3 waves per SIMD — at 262 144 envs their fourth wave queues instead of being resident.
+    static constexpr int kMinWavesPerEU = VARIANT >= 2 ? 4 : 3;
     __device__ static constexpr const IpModel& km() { return VARIANT >= 2 ? kIpHanging : kIpUpright; }
     // The dynamics only use mpr * sin(phi) and mpr * cos(phi): the float64 kernels stage the {sin,cos} table
     // pre-multiplied by the pole's mass moment (emei_device.h:stage_trig_table), the carry holds the products
@@ -275,6 +324,7 @@ struct InvPend {
         const R dt = (R)p.dt;
         // the new angle needs only the OLD angular velocity, so its sin/cos is started first and lands under the dynamics
         const R x_old = s[0], v_old = s[2], om_old = s[3];
+        [[maybe_unused]] const R th_old = s[1];
         s[0] = fma_r(dt, v_old, x_old);
         s[1] = fma_r(dt, om_old, s[1]);
         R P = c.sn, Q = c.cs;
@@ -290,7 +340,16 @@ struct InvPend {
         static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
         const R dist = (R)m.x_hi - fabs(x_old);
         EMEI_STAT_WAVE(19);  // substeps (waves)
-        if (dist < R(0)) {
+        // Balancing variants: the hinge's +-90 degree stop (a post-terminal state): the whole wave takes the general two-row
+        // solve (ip_limit_rows handles the slider row too); otherwise the one-row closed form below
+        bool general = false;
+        if constexpr (VARIANT < 2) {
+            static_assert(m.th_lo == -m.th_hi, "symmetric hinge range");
+            general = __ballot(fabs(th_old) > (R)m.th_hi) != 0ull;
+        }
+        if (__builtin_expect(general, 0)) {
+            ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
+        } else if (dist < R(0)) {
             EMEI_STAT_WAVE(20);  // ... with the limit block
             EMEI_STAT_LANE(21);  // lanes beyond the rail
             const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one

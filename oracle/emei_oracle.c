@@ -208,6 +208,8 @@ typedef struct {
     double mc, mp, r, Icom, phi0; /* cart mass, pole mass, |com|, inertia about com (y), com angle */
     double g, gear, ctrl_lo, ctrl_hi, x_lo, x_hi;
     double invweight_slider; /* dof_invweight0 of the slider (at qpos0 of the compiled model) */
+    double invweight_hinge;  /* dof_invweight0 of the hinge */
+    double th_lo, th_hi;     /* hinge range (:17, -90 90 degrees; the SwingUp variants free it, inverted_pendulum.py:135-137) */
     /* soft joint-limit constraint: default solref (0.02, 1), solimp (0.9, 0.95, 0.001, 0.5, 2) */
     double timeconst, dampratio, dmin, dmax, width;
 } ip_model_t;
@@ -242,6 +244,8 @@ EXPORT void emei_oracle_ip_model(ip_model_t* m) {
     double c = cos(m->phi0);
     double M11 = m->mc + m->mp, M12 = m->mp * m->r * c, M22 = m->Icom + m->mp * m->r * m->r;
     m->invweight_slider = M22 / (M11 * M22 - M12 * M12);
+    m->invweight_hinge = M11 / (M11 * M22 - M12 * M12);
+    m->th_lo = -M_PI / 2, m->th_hi = M_PI / 2;
 }
 
 EXPORT int emei_oracle_ip_model_size(void) { return (int)sizeof(ip_model_t); }
@@ -278,29 +282,47 @@ static void ip_accel(const void* ctx, double dt, double hd, const double* q, con
     double det = M11 * M22 - M12 * M12;
     double a0 = (M22 * f1 - M12 * f2) / det; /* unconstrained ("smooth") accelerations */
     double a1 = (M11 * f2 - M12 * f1) / det;
-    /* Soft slider-limit constraint.  Boundary variants terminate as soon as x leaves (x_lo, x_hi)
-     * (inverted_pendulum.py:106-111,179-183) but MuJoCo still applies the limit force while the
-     * reference keeps stepping, so it is evaluated for every variant. */
-    double dist = 0, J = 0;
-    if (q[0] - m->x_lo < 0)
-        dist = q[0] - m->x_lo, J = 1.0;
-    else if (m->x_hi - q[0] < 0)
-        dist = m->x_hi - q[0], J = -1.0;
-    if (J != 0.0) {
-        double tc = m->timeconst < 2 * dt ? 2 * dt : m->timeconst; /* refsafe */
-        double xx = fabs(dist) / m->width;
-        double y = xx >= 1 ? 1.0 : (xx <= 0.5 ? 2 * xx * xx : 1 - 2 * (1 - xx) * (1 - xx));
-        double imp = m->dmin + y * (m->dmax - m->dmin);
-        double K = 1.0 / (m->dmax * m->dmax * tc * tc * m->dampratio * m->dampratio);
-        double B = 2.0 / (m->dmax * tc);
-        double aref = -B * (J * v[0]) - K * imp * dist;
-        double A = M22 / det; /* J M^-1 J^T, J = +-e_0 */
-        double R = (1 - imp) / imp * m->invweight_slider;
-        double force = (aref - J * a0) / (A + R);
-        if (force > 0) {
-            a0 += (M22 / det) * J * force;
-            a1 += (-M12 / det) * J * force;
-        }
+    /* Soft joint-limit constraints (mjCNSTR_LIMIT_JOINT, margin 0, default solref / solimp): the slider's range (:14) for every
+     * variant — Boundary variants terminate as soon as x leaves (x_lo, x_hi) (inverted_pendulum.py:106-111,179-183) but MuJoCo
+     * still applies the limit force while the reference keeps stepping — and the hinge's range of +-90 degrees (:17; every
+     * joint is `limited` by the file's default) for the Balancing variants, which only a POST-terminal state reaches (Rebound
+     * terminates at cos theta < 0.9, Boundary at cos theta < 0); the SwingUp variants set the hinge range to +-inf.
+     * Each row i: cost D_i / 2 min(0, J_i a - aref_i)^2 with D_i = 1 / R_i, R_i = (1 - imp) / imp dof_invweight0.  With at
+     * most two rows the minimiser is found by enumerating the active sets of the 2 x 2 linear complementarity problem
+     *   f >= 0,  (A + R) f - b >= 0,  f' ((A + R) f - b) = 0,   A = J M^-1 J',  b_i = aref_i - J_i a0
+     * (A + R positive definite: exactly one of the four sets is consistent). */
+    const double tc = m->timeconst < 2 * dt ? 2 * dt : m->timeconst; /* refsafe */
+    const double K = 1.0 / (m->dmax * m->dmax * tc * tc * m->dampratio * m->dampratio), B = 2.0 / (m->dmax * tc);
+    double Jr[2] = {0, 0}, b[2] = {0, 0}, Rr[2] = {1, 1}; /* row 0: slider, row 1: hinge; J = 0: the row does not exist */
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && ip_is_swingup(variant)) continue;
+        const double lo = i == 0 ? m->x_lo : m->th_lo, hi = i == 0 ? m->x_hi : m->th_hi;
+        double dist;
+        if (q[i] - lo < 0) dist = q[i] - lo, Jr[i] = 1.0;
+        else if (hi - q[i] < 0) dist = hi - q[i], Jr[i] = -1.0;
+        else continue;
+        const double xx = fabs(dist) / m->width;
+        const double y = xx >= 1 ? 1.0 : (xx <= 0.5 ? 2 * xx * xx : 1 - 2 * (1 - xx) * (1 - xx));
+        const double imp = m->dmin + y * (m->dmax - m->dmin);
+        const double aref = -B * (Jr[i] * v[i]) - K * imp * dist;
+        b[i] = aref - Jr[i] * (i == 0 ? a0 : a1);
+        Rr[i] = (1 - imp) / imp * (i == 0 ? m->invweight_slider : m->invweight_hinge);
+    }
+    if (Jr[0] != 0.0 || Jr[1] != 0.0) {
+        const double A00 = M22 / det, A11 = M11 / det, A01 = Jr[0] * Jr[1] * (-M12 / det);
+        const double H00 = A00 + Rr[0], H11 = A11 + Rr[1];
+        double f0 = 0, f1 = 0;
+        const int has0 = Jr[0] != 0.0, has1 = Jr[1] != 0.0;
+        const double s0 = b[0] / H00, s1 = b[1] / H11; /* single-row solutions */
+        const double d2 = H00 * H11 - A01 * A01;
+        const double t0 = (H11 * b[0] - A01 * b[1]) / d2, t1 = (H00 * b[1] - A01 * b[0]) / d2; /* both rows */
+        if (has0 && has1 && t0 > 0 && t1 > 0) f0 = t0, f1 = t1;
+        else if (has0 && s0 > 0 && !(has1 && b[1] - A01 * s0 > 0)) f0 = s0;
+        else if (has1 && s1 > 0 && !(has0 && b[0] - A01 * s1 > 0)) f1 = s1;
+        /* generalised force J' f through M^-1 */
+        const double g0 = Jr[0] * f0, g1 = Jr[1] * f1;
+        a0 += (M22 * g0 - M12 * g1) / det;
+        a1 += (M11 * g1 - M12 * g0) / det;
     }
     qacc[0] = a0, qacc[1] = a1;
 }
@@ -375,8 +397,18 @@ EXPORT void emei_oracle_ip_accel_custom(double mc, double mp, double r, double I
     m.mc = mc, m.mp = mp, m.r = r, m.Icom = Icom, m.phi0 = 0.0, m.g = g;
     m.gear = 1.0, m.ctrl_lo = -INFINITY, m.ctrl_hi = INFINITY, m.x_lo = -INFINITY, m.x_hi = INFINITY;
     m.timeconst = 0.02, m.dampratio = 1.0, m.dmin = 0.9, m.dmax = 0.95, m.width = 0.001, m.invweight_slider = 1.0;
+    m.invweight_hinge = 1.0, m.th_lo = -INFINITY, m.th_hi = INFINITY; /* no limit row: the smooth equations only */
     ip_ctx_t ctx = {&m, 0};
     ip_accel(&ctx, 0.02, 0.0, q, v, &force, acc);
+}
+
+/* forward dynamics of one state with the model's own constants and limits: (x'', theta'') — for the tests that check the
+ * limit rows through their optimality conditions */
+EXPORT void emei_oracle_ip_accel(int variant, double dt, const double* q, const double* v, double ctrl, double* acc) {
+    ip_model_t m;
+    emei_oracle_ip_model(&m);
+    ip_ctx_t ctx = {&m, variant};
+    ip_accel(&ctx, dt, 0.0, q, v, &ctrl, acc);
 }
 
 EXPORT void emei_oracle_ip_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,

@@ -191,7 +191,7 @@ def body_init(seed, env, episode, nv, sigma_pos, sigma_vel=None, shared=False):
 class IPModel(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "mc", "mp", "r", "Icom", "phi0", "g", "gear", "ctrl_lo", "ctrl_hi", "x_lo", "x_hi",
-        "invweight_slider", "timeconst", "dampratio", "dmin", "dmax", "width")]
+        "invweight_slider", "invweight_hinge", "th_lo", "th_hi", "timeconst", "dampratio", "dmin", "dmax", "width")]
 
 
 def ip_model():
@@ -213,6 +213,16 @@ def ip_step(variant, state, action, freq_rate=1, dt=0.02, opt=None):
                                  _p(st, C.c_double), _p(act, C.c_double), _p(obs, C.c_double), _p(rew, C.c_double),
                                  _p(term, C.c_uint8), _o(opt))
     return st, obs, rew, term.astype(bool)
+
+
+def ip_accel(variant, q, v, ctrl, dt=0.02):
+    """(x'', theta'') of the oracle's InvertedPendulum at one state, limits included."""
+    q = np.ascontiguousarray(q, np.float64).reshape(2)
+    v = np.ascontiguousarray(v, np.float64).reshape(2)
+    acc = np.empty(2)
+    lib().emei_oracle_ip_accel(C.c_int(IP_VARIANTS[variant]), C.c_double(dt), _p(q, C.c_double), _p(v, C.c_double), C.c_double(ctrl),
+                               _p(acc, C.c_double))
+    return acc
 
 
 def ip_accel_custom(mc, mp, r, Icom, g, q, v, force):
