@@ -208,13 +208,13 @@ constexpr IpModel ip_make_model(bool swingup) {
 __device__ constexpr IpModel kIpUpright = ip_make_model(false), kIpHanging = ip_make_model(true);
 
 // emei_model_constants (include/emei_hip.h): [gravity, mc, mp, Icom, r, phi0, gear, ctrl_lo, ctrl_hi, x_lo, x_hi, solref tc,
-// solimp dmin, dmax, width]
+// solimp dmin, dmax, width, hinge range lo, hi (Balancing variants)]
 inline int ip_xml_constants(double* out) {
     constexpr IpModel m = ip_make_model(false);
-    const double v[15] = {m.gravity, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.solref_tc,
-                          m.dmin, m.dmax, m.width};
-    for (int i = 0; i < 15; ++i) out[i] = v[i];
-    return 15;
+    const double v[17] = {m.gravity, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.solref_tc,
+                          m.dmin, m.dmax, m.width, m.th_lo, m.th_hi};
+    for (int i = 0; i < 17; ++i) out[i] = v[i];
+    return 17;
 }
 
 // Joint-limit rows of the InvertedPendulum in their general form — the slider's range and, for the Balancing variants, the hinge's

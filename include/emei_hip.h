@@ -159,8 +159,9 @@ EMEI_API int emei_abi_version(void);
  * can pin them to the reference's only data for the MuJoCo-backed bodies (the XML files under emei/envs/mujoco/assets;
  * tests/test_model_constants.py).  Writes at most `capacity` doubles to `out`, returns the count (negative = error;
  * EMEI_ERR_UNSUPPORTED for the classic-control CartPole, whose constants are cartpole.py:22-27 literals).  Host only.
- *   InvertedPendulum x4 (15): gravity, cart mass, pole mass, pole inertia about its com, com distance from the hinge, tilt of
- *       the pole axis at theta = 0, gear, ctrlrange lo, hi, slider range lo, hi, limit solref time constant, solimp dmin, dmax, width
+ *   InvertedPendulum x4 (17): gravity, cart mass, pole mass, pole inertia about its com, com distance from the hinge, tilt of
+ *       the pole axis at theta = 0, gear, ctrlrange lo, hi, slider range lo, hi, limit solref time constant, solimp dmin, dmax, width,
+ *       hinge range lo, hi (rad; a limit row of the Balancing variants, freed by the SwingUp variants)
  *   InvertedDoublePendulum x4 (17): gravity x, gravity z, cart mass, pole mass, pole inertia about its com, pole com distance,
  *       pole-1 length, gear, ctrlrange lo, hi, slider range lo, hi, joint margin, limit solref time constant, solimp dmin, dmax, width
  *   HalfCheetahRunning (148) / HopperRunning (84), nb = 7 / 4 bodies, ng = 8 / 4 capsules, nj = 6 / 3 actuated hinges:

@@ -255,10 +255,10 @@ EXPORT int emei_oracle_ip_model_size(void) { return (int)sizeof(ip_model_t); }
 EXPORT int emei_oracle_ip_xml_constants(double* out) {
     ip_model_t m;
     emei_oracle_ip_model(&m);
-    const double v[15] = {m.g, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.timeconst,
-                          m.dmin, m.dmax, m.width};
+    const double v[17] = {m.g, m.mc, m.mp, m.Icom, m.r, m.phi0, m.gear, m.ctrl_lo, m.ctrl_hi, m.x_lo, m.x_hi, m.timeconst,
+                          m.dmin, m.dmax, m.width, m.th_lo, m.th_hi};
     memcpy(out, v, sizeof(v));
-    return 15;
+    return 17;
 }
 
 static inline int ip_is_swingup(int variant) { return variant >= 2; }

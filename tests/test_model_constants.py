@@ -156,7 +156,7 @@ def ip_expected(x):
     assert all(_or(v, 0.0) == 0.0 for key in ("damping", "armature", "stiffness") for v in x[f"ip_joint_{key}"])
     return np.array([-x["ip_gravity"][2], capsule_mass(*x["ip_geom_size"][cart, :2]), capsule_mass(rp, half), capsule_inertia_perp(rp, half),
                      half, np.arctan2(d[0], d[2]), x["ip_act_gear"][0], *x["ip_act_ctrlrange"][0], *x["ip_joint_range"][slider],
-                     SOLREF_TC, *SOLIMP])
+                     SOLREF_TC, *SOLIMP, *(x["ip_joint_range"][1 - slider] * (np.pi / 180 if x["ip_angle_degree"] else 1.0))])
 
 
 def dp_expected(x):
@@ -198,9 +198,11 @@ def test_inverted_pendulum_matches_the_xml(xml):
     for env_id in (2, 3, 4, 5):
         _close(kernel_constants(env_id), want)
     # SwingUp's _update_model turns the pole body by pi and frees the hinge (inverted_pendulum.py:135-137); the Balancing
-    # variants keep the file's hinge range of +-90 degrees, which only a post-terminal state can reach
+    # variants keep the file's hinge range of +-90 degrees: a second limit row since round 3 (oracle: ip_model.th_lo / th_hi)
     hinge, = [j for j in range(2) if xml["ip_joint_is_hinge"][j]]
     assert list(xml["ip_joint_range"][hinge]) == [-90.0, 90.0] and xml["ip_angle_degree"]
+    m = O.ip_model()
+    assert (m.th_lo, m.th_hi) == (-np.pi / 2, np.pi / 2)
 
 
 def test_inverted_double_pendulum_matches_the_xml(xml):
