@@ -1,5 +1,5 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercising the shard partition and the all-gather
-of the batched observation return (RCCL on GPUs)."""
+"""The N>1 path on CPU: world_size-2 and -4 gloo processes exercising the shard partition and the all-gather
+of the batched observation return (RCCL on GPUs; the 8-rank run itself is the driver's)."""
 import os
 import socket
 import sys
@@ -42,9 +42,10 @@ def _worker(rank, world, port, n_per_rank, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_allgather_obs_world2():
-    world, n = 2, 96
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_allgather_obs(world):
+    n = 96
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -55,7 +56,7 @@ def test_allgather_obs_world2():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    assert res == [(0, True, (world * n, 4)), (1, True, (world * n, 4))]
+    assert res == [(r, True, (world * n, 4)) for r in range(world)]
 
 
 def _xchg_worker(rank, world, port, q):
@@ -88,9 +89,9 @@ def _xchg_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_obs_exchange_chunks_world2():
-    world = 2
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_obs_exchange_chunks(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -101,7 +102,7 @@ def test_obs_exchange_chunks_world2():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    assert res == [(0, True, 9), (1, True, 9)]
+    assert res == [(r, True, 9) for r in range(world)]
 
 
 def test_shard_bounds_cover_and_balance():
