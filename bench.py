@@ -72,10 +72,26 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library loads
     rng = np.random.default_rng(1)
     if env.startswith("CartPole"):
+        # the CPU twin of the timed call: a fused multi-step rollout with auto-reset and TimeLimit in C (blocks of envs over the
+        # OpenMP threads, no Python between steps), writing the same float32 obs / reward / uint8 done per env-step into
+        # buffers that stay allocated — bit-identical to the per-step oracle (tests/test_oracle_golden.py)
         variant = "swingup" if env == "CartPoleSwingUp" else "balancing"
+        max_steps = 1000 if variant == "swingup" else 500
         st = O.cartpole_init_state_host(variant, 0, n)
-        acts = rng.integers(2, size=(64, n)).astype(np.int32)
-        step = lambda s, a: O.cartpole_step(variant, s, a, freq_rate, dt)[0]
+        Tc = 50
+        acts = rng.integers(2, size=(Tc, n)).astype(np.uint8)
+        r = O.cartpole_rollout_autoreset(variant, st, acts, 0, None, max_steps, freq_rate, dt)  # warm: build, page in the outputs
+        t0 = time.perf_counter()
+        calls = 0
+        while True:
+            r = O.cartpole_rollout_autoreset(variant, r["state"], acts, 0, None, max_steps, freq_rate, dt, r["steps"], r["episode"], reuse=r)
+            calls += 1
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                break
+        return {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, auto-reset, TimeLimit {max_steps}, "
+                          f"float32 obs / reward and uint8 done written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
     else:
         opt = O.opts(integrator, solver=solver)
         if "InvertedDoublePendulum" in env:

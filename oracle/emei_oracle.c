@@ -192,6 +192,47 @@ EXPORT void emei_oracle_cartpole_init_f32(int variant, uint64_t seed, uint64_t e
     if (variant == 0) s[2] += (float)M_PI;
 }
 
+/* The CPU twin of the fused device rollout WITH auto-reset (what bench.py times and tests/test_gpu_bench_shape.py checks):
+ * T steps of base_control.py:61-83 per env with the float64 reference arithmetic above; TimeLimit (register_env.py:14-23:
+ * `truncated` after max_steps steps of an episode, 0 = never); on done (terminal | truncated) the env is re-initialised from
+ * the device reset generator's specification, cartpole_init_f32(seed, global env index, episode + 1).
+ *   state [n,4] float64 in/out, steps [n] int32 in/out, episode [n] uint32 in/out, env_ids [n] global indices,
+ *   actions [T,n] uint8; outputs as the device writes them: obs [T,n,4] float32 (the state after the step, before any reset),
+ *   reward [T,n] float32, done [T,n] uint8 (bit 0 terminal, bit 1 truncated); any output may be NULL.
+ * Parallel over blocks of 64 envs (no per-step fork / join). */
+EXPORT void emei_oracle_cartpole_rollout_autoreset(int variant, int64_t n, int T, int freq_rate, double dt, int max_steps, uint64_t seed,
+                                                   const int64_t* env_ids, double* state, int32_t* steps, uint32_t* episode,
+                                                   const uint8_t* actions, float* obs, float* reward, uint8_t* done) {
+    /* blocks of envs (static over the threads), steps outermost inside a block: a block's state (64 envs x 32 B) stays in the
+     * core's L1 and every output row is written in contiguous 64-env pieces */
+    const int64_t BLK = 64, nblk = (n + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t lo = b * BLK, hi = lo + BLK < n ? lo + BLK : n;
+        for (int t = 0; t < T; ++t) {
+            for (int64_t i = lo; i < hi; ++i) {
+                double y[5];
+                memcpy(y, state + 4 * i, 4 * sizeof(double));
+                y[4] = actions[(int64_t)t * n + i] == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
+                cp_ode_euler(y, dt, freq_rate);
+                const int32_t st = ++steps[i];
+                const uint8_t d = (uint8_t)(cp_terminal(variant, y) | ((max_steps > 0 && st >= max_steps) ? 2 : 0));
+                const int64_t row = (int64_t)t * n + i;
+                if (obs) for (int k = 0; k < 4; ++k) obs[4 * row + k] = (float)y[k];
+                if (reward) reward[row] = (float)cp_reward(variant, y);
+                if (done) done[row] = d;
+                if (d) {
+                    float f[4];
+                    steps[i] = 0;
+                    emei_oracle_cartpole_init_f32(variant, seed, (uint64_t)(env_ids ? env_ids[i] : i), ++episode[i], f);
+                    for (int k = 0; k < 4; ++k) y[k] = (double)f[k];
+                }
+                memcpy(state + 4 * i, y, 4 * sizeof(double));
+            }
+        }
+    }
+}
+
 #include "integrators.h"
 #define boxmuller oracle_boxmuller /* float32 Box-Muller of the device reset (integrators.h) */
 

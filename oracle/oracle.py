@@ -105,6 +105,33 @@ def cartpole_init_state_host(variant, seed, batch_size):
     return s
 
 
+def cartpole_rollout_autoreset(variant, state, actions, seed, env_ids=None, max_steps=0, freq_rate=1, dt=0.02, steps=None, episode=None,
+                               want=("obs", "reward", "done"), reuse=None):
+    """T fused steps with device-style auto-reset, in C over all envs (the CPU twin of emei_rollout with EMEI_FLAG_AUTO_RESET).
+    state [n,4] float64 (copied), actions [T,n] uint8 -> dict(obs [T,n,4] f32, reward [T,n] f32, done [T,n] u8, state [n,4] f64,
+    steps [n] i32, episode [n] u32); `want` selects which per-step outputs are produced; `reuse` = the dict of a previous call
+    of the same shape, whose output buffers are written again (a timing loop does not page in fresh memory per call)."""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
+    n = st.shape[0]
+    act = np.ascontiguousarray(actions, dtype=np.uint8).reshape(-1, n)
+    T = act.shape[0]
+    sc = np.zeros(n, np.int32) if steps is None else np.array(steps, np.int32, copy=True)
+    ep = np.zeros(n, np.uint32) if episode is None else np.array(episode, np.uint32, copy=True)
+    ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int64)
+    if reuse is not None and reuse.get("obs") is not None and reuse["obs"].shape == (T, n, 4):
+        obs, rew, dn = reuse["obs"], reuse["reward"], reuse["done"]  # output buffers of a previous call (already paged in)
+    else:
+        obs = np.empty((T, n, 4), np.float32) if "obs" in want else None
+        rew = np.empty((T, n), np.float32) if "reward" in want else None
+        dn = np.empty((T, n), np.uint8) if "done" in want else None
+    lib().emei_oracle_cartpole_rollout_autoreset(
+        C.c_int(CARTPOLE_VARIANTS[variant]), C.c_int64(n), C.c_int(T), C.c_int(int(freq_rate)), C.c_double(float(dt)), C.c_int(int(max_steps)),
+        C.c_uint64(int(seed)), _p(ids, C.c_int64) if ids is not None else None, _p(st, C.c_double), _p(sc, C.c_int32), _p(ep, C.c_uint32),
+        _p(act, C.c_uint8), _p(obs, C.c_float) if obs is not None else None, _p(rew, C.c_float) if rew is not None else None,
+        _p(dn, C.c_uint8) if dn is not None else None)
+    return dict(obs=obs, reward=rew, done=dn, state=st, steps=sc, episode=ep)
+
+
 def philox(seed, env, episode, block=0):
     out = (C.c_uint32 * 4)()
     lib().emei_oracle_philox(C.c_uint64(seed), C.c_uint64(env), C.c_uint32(episode), C.c_uint32(block), out)

@@ -112,6 +112,41 @@ def test_bench_shape_65536x1000_vs_oracle():
     _properties(obs, rew, done, sr.engine)
 
 
+def test_every_env_of_config2_against_the_c_twin():
+    """BASELINE configs[1], EVERY env and EVERY step (65 536 x 1000 = 65.5 M env-steps, not a sample): bench.py's exact call
+    against the oracle's fused C rollout with the same reset injection (oracle.cartpole_rollout_autoreset: bit-identical to the
+    per-step oracle, tests/test_oracle_golden.py).  A trajectory can leave the oracle's only where a float64 derivative
+    lands within ~1e-16 of a float32 rounding boundary (cartpole.py:60 rounds it to float32; the kernel's sin / cos differ from
+    libm's in the last bit): expected 0.5 such events in 2.6e8 roundings, after which THAT env's chaotic trajectory drifts —
+    so at most two envs may differ, everything else must agree: done masks bit for bit, observations and rewards to 1e-5."""
+    from emei_amd import _lib as L
+    from emei_amd.sharding import ShardedRollout
+    from oracle import oracle as O
+
+    N, T = 65536, 1000
+    sr = ShardedRollout("CartPoleSwingUp", N, T, freq_rate=1, real_time_scale=0.02, precision="ref", device=torch.cuda.current_device(), seed=0)
+    sr.make_synthetic_inputs()
+    s0 = sr.engine.get_state().cpu().numpy()
+    obs, rew, done = sr.engine.rollout(sr.actions, auto_reset=True, out=sr.out)
+    torch.cuda.synchronize()
+    assert sr.engine.last_kernel() == L.KERNEL_PEND_STAGED_FREQ1
+    o = O.cartpole_rollout_autoreset("swingup", s0, sr.actions.cpu().numpy(), 0, None, 1000)
+    g_done = done.cpu().numpy()
+    bad = (g_done != o["done"]).any(axis=0)
+    g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+    with np.errstate(all="ignore"):
+        e_obs = (np.abs(g_obs.astype(np.float64) - o["obs"]) / np.maximum(np.abs(o["obs"]), 1e-3)).max(axis=(0, 2))
+        e_rew = (np.abs(g_rew.astype(np.float64) - o["reward"]) / np.maximum(np.abs(o["reward"]), 1e-3)).max(axis=0)
+    bad |= ~(e_obs <= RTOL) | ~(e_rew <= RTOL)
+    assert int(bad.sum()) <= 2, (int(bad.sum()), np.nonzero(bad)[0][:8], float(np.nanmax(e_obs)), float(np.nanmax(e_rew)))
+    ok = ~bad
+    st = sr.engine.get_state().cpu().numpy()
+    assert rel_err(st[ok], o["state"][ok], floor=1e-3) <= RTOL
+    steps, epi = sr.engine.get_counters()
+    assert np.array_equal(steps.cpu().numpy()[ok], o["steps"][ok]) and np.array_equal(epi.cpu().numpy()[ok], o["episode"][ok].astype(np.int64))
+    assert int((o["done"] & 1).astype(bool).sum()) > N  # episodes end and restart inside the horizon: the reset path is exercised everywhere
+
+
 def test_bench_shape_131072x1000_vs_oracle():
     """configs[4]'s per-GPU shard (1 048 576 / 8), as rank 5 of 8: global env offset 5 * 131 072."""
     sr, obs, rew, done = _bench_pass_vs_oracle(131072, rank=5, world=8)

@@ -119,3 +119,27 @@ def test_gaussian_draws_follow_the_stated_box_muller_spec():
             want += [np.float32(rad * np.cos(2 * np.pi * t)), np.float32(rad * np.sin(2 * np.pi * t))]
         got = O.ip_init_f32(seed, env, epi, 1.0)  # sigma = 1: the four normals themselves (x, theta, v, omega)
         assert np.array_equal(np.asarray(got, np.float32), np.asarray(want, np.float32)), (seed, env, epi, got, want)
+
+
+def test_fused_c_rollout_with_auto_reset_equals_the_per_step_oracle():
+    """oracle.cartpole_rollout_autoreset (the CPU twin of the fused device rollout: bench.py's cpu_baseline and the all-env
+    GPU parity test) against the per-step oracle with Python-side reset injection (conftest.oracle_autoreset_rollout):
+    identical done masks, counters and float64 state; the float32 outputs are the float64 ones rounded."""
+    from conftest import oracle_autoreset_rollout
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(5)
+    for variant, max_steps, fr in (("balancing", 50, 1), ("swingup", 40, 2)):
+        n, T = 200, 160
+        s0 = O.cartpole_init_state_host(variant, 3, n)
+        acts = rng.integers(2, size=(T, n)).astype(np.uint8)
+        ids = np.arange(5000, 5000 + n)
+        a_obs, a_rew, a_done, a_st = oracle_autoreset_rollout(variant, s0, acts, 11, ids, max_steps, fr)
+        b = O.cartpole_rollout_autoreset(variant, s0, acts, 11, ids, max_steps, fr)
+        assert np.array_equal(a_done, b["done"]) and np.array_equal(a_st, b["state"])
+        assert np.array_equal(a_obs.astype(np.float32), b["obs"]) and np.array_equal(a_rew.astype(np.float32), b["reward"])
+        assert int(b["done"].astype(bool).sum()) > n and (b["done"] & 2).any()
+        # continuing from the returned counters = one longer call
+        c1 = O.cartpole_rollout_autoreset(variant, s0, acts[:70], 11, ids, max_steps, fr)
+        c2 = O.cartpole_rollout_autoreset(variant, c1["state"], acts[70:], 11, ids, max_steps, fr, steps=c1["steps"], episode=c1["episode"])
+        assert np.array_equal(c2["state"], b["state"]) and np.array_equal(np.concatenate([c1["done"], c2["done"]]), b["done"])
