@@ -78,7 +78,7 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
         variant = "swingup" if env == "CartPoleSwingUp" else "balancing"
         max_steps = 1000 if variant == "swingup" else 500
         st = O.cartpole_init_state_host(variant, 0, n)
-        Tc = 50
+        Tc = 200
         acts = rng.integers(2, size=(Tc, n)).astype(np.uint8)
         r = O.cartpole_rollout_autoreset(variant, st, acts, 0, None, max_steps, freq_rate, dt)  # warm: build, page in the outputs
         t0 = time.perf_counter()
