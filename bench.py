@@ -60,6 +60,26 @@ def algorithmic_bytes_per_env_step(obs_dim, act_bytes):
     return act_bytes + 4 * obs_dim + 4 + 1
 
 
+def host_cpu_share():
+    """Threads worth starting on this host: the affinity mask capped by the cgroup's CPU quota.  A one-GPU box shows 256
+    logical CPUs but grants 16 CPUs of time (cpu.max 1600000 100000): 256 OpenMP threads on that quota are throttled to a third
+    of what 16 threads reach (profiles/r03_cpu_threads.txt)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                cores = min(cores, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", budget_s=12.0):
     """The CPU oracle ("port": the C restatement of the reference's step arithmetic — CartPole pinned bit-exact to the
     reference by tests/golden, the MuJoCo-backed bodies a restatement of MuJoCo's published algorithm) timed on this
@@ -68,7 +88,7 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
 
     from oracle import oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cpu_share()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library loads
     rng = np.random.default_rng(1)
     if env.startswith("CartPole"):
@@ -92,39 +112,40 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
         return {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
                 "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, auto-reset, TimeLimit {max_steps}, "
                           f"float32 obs / reward and uint8 done written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+    # the MuJoCo-backed bodies: the same kind of twin — Tc env-steps per C call (blocks of envs over the OpenMP threads, no Python
+    # between steps), float32 obs / reward and uint8 terminal written per env-step, no reset (as the per-step reference) —
+    # step for step the per-step oracle's arithmetic (tests/test_oracle_golden.py)
+    opt = O.opts(integrator, solver=solver)
+    if "InvertedDoublePendulum" in env:
+        kind, variant = "dp", [k for k in O.DP_VARIANTS if k.replace("_", "") in env.lower().replace("inverteddoublependulum", "")][0]
+        st, lo, nu, Tc = rng.standard_normal((n, 6)) * 5e-3, 1.0, (), 25
+    elif "InvertedPendulum" in env:
+        kind, variant = "ip", [k for k in O.IP_VARIANTS if k.replace("_", "") in env.lower().replace("invertedpendulum", "")][0]
+        st, lo, nu, Tc = rng.standard_normal((n, 4)) * 5e-3, 3.0, (), 25
+    elif env == "HalfCheetahRunning":
+        kind, variant = "cheetah", None
+        st, lo, nu, Tc = rng.standard_normal((n, 18)) * 0.1, 1.0, (6,), 5
+    elif env == "HopperRunning":
+        kind, variant = "hopper", None
+        st, lo, nu, Tc = rng.standard_normal((n, 12)) * 5e-3, 1.0, (3,), 5
+        st[:, 1] += 1.25
     else:
-        opt = O.opts(integrator, solver=solver)
-        if "InvertedDoublePendulum" in env:
-            variant = [k for k in O.DP_VARIANTS if k.replace("_", "") in env.lower().replace("inverteddoublependulum", "")][0]
-            st, acts = rng.standard_normal((n, 6)) * 5e-3, rng.uniform(-1, 1, (64, n))
-            step = lambda s, a: O.dpend_step(variant, s, a, freq_rate, dt, opt)[0]
-        elif "InvertedPendulum" in env:
-            variant = [k for k in O.IP_VARIANTS if k.replace("_", "") in env.lower().replace("invertedpendulum", "")][0]
-            st, acts = rng.standard_normal((n, 4)) * 5e-3, rng.uniform(-3, 3, (64, n))
-            step = lambda s, a: O.ip_step(variant, s, a, freq_rate, dt, opt)[0]
-        elif env == "HalfCheetahRunning":
-            st, acts = rng.standard_normal((n, 18)) * 0.1, rng.uniform(-1, 1, (64, n, 6))
-            step = lambda s, a: O.cheetah_step(s, a, freq_rate, dt, opt)[0]
-        elif env == "HopperRunning":
-            st = rng.standard_normal((n, 12)) * 5e-3
-            st[:, 1] += 1.25
-            acts = rng.uniform(-1, 1, (64, n, 3))
-            step = lambda s, a: O.hopper_step(s, a, freq_rate, dt, opt)[0]
-        else:
-            return None
-    st = step(st, acts[0])  # warm (build + first touch)
+        return None
+    acts = rng.uniform(-lo, lo, (Tc, n) + nu).astype(np.float32)
+    r = O.body_rollout(kind, variant, st, acts[:1], freq_rate, dt, opt)  # warm: build the library, first touch of the state
+    r = O.body_rollout(kind, variant, r["state"], acts, freq_rate, dt, opt)  # page in the outputs
     t0 = time.perf_counter()
-    steps = 0
+    calls = 0
     while True:
-        st = step(st, acts[steps % 64])
-        steps += 1
+        r = O.body_rollout(kind, variant, r["state"], acts, freq_rate, dt, opt, reuse=r)
+        calls += 1
         el = time.perf_counter() - t0
         if el > budget_s:
             break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of {n} {env} envs (freq_rate {freq_rate}, dt {dt}, {integrator}"
-                      + ("" if env.startswith("CartPole") or "Pendulum" in env else f", {solver} solver")
-                      + f") with the C oracle (float64, OpenMP x{cores}, no reset), {el:.1f} s"}
+    return {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, {integrator}"
+                      + ("" if "Pendulum" in env else f", {solver} solver")
+                      + f", no reset, float32 obs / reward and uint8 terminal written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
 
 
 def self_launch(n_gpus):

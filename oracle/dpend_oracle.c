@@ -160,6 +160,34 @@ EXPORT void dpend_oracle_step_ex(int variant, int64_t n, int freq_rate, double d
     }
 }
 
+/* T env-steps in one call (bench.py's cpu_baseline; see emei_oracle_ip_rollout): float32 actions [T,n], outputs obs float32
+ * [T,n,6], reward float32 [T,n], terminal uint8 [T,n] (any may be NULL); no reset */
+EXPORT void dpend_oracle_rollout(int variant, int64_t n, int T, int freq_rate, double dt, double* state, const float* actions,
+                                 float* obs, float* reward, uint8_t* terminal, const oracle_opts_t* opts) {
+    dp_model_t m;
+    dpend_oracle_model(&m, dt);
+    dp_ctx_t ctx = {&m, variant >= 2 ? M_PI : 0.0};
+    const int64_t BLK = 64, nblk = (n + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t lo = b * BLK, hi = lo + BLK < n ? lo + BLK : n;
+        for (int t = 0; t < T; ++t)
+            for (int64_t i = lo; i < hi; ++i) {
+                double* s = state + 6 * i;
+                const double a = (double)actions[(int64_t)t * n + i];
+                oracle_env_step(dp_accel, &ctx, 3, freq_rate, dt, opts, i, s, s + 3, &a);
+                const double o[6] = {s[0], quirk_wrap(s[1]), quirk_wrap(s[2]), s[3], s[4], s[5]};
+                double r;
+                uint8_t d;
+                dp_reward_terminal(variant, o, &r, &d);
+                const int64_t row = (int64_t)t * n + i;
+                if (obs) for (int k = 0; k < 6; ++k) obs[6 * row + k] = (float)o[k];
+                if (reward) reward[row] = (float)r;
+                if (terminal) terminal[row] = d;
+            }
+    }
+}
+
 EXPORT void dpend_oracle_step(int variant, int64_t n, int freq_rate, double dt, double* state, const double* action,
                               double* obs, double* reward, uint8_t* terminal) {
     dpend_oracle_step_ex(variant, n, freq_rate, dt, state, action, obs, reward, terminal, NULL);

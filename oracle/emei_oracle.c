@@ -428,6 +428,34 @@ EXPORT void emei_oracle_ip_step_ex(int variant, int64_t n, int freq_rate, double
     }
 }
 
+/* T env-steps in one call (bench.py's cpu_baseline: no Python and no fork / join between steps): blocks of 64 envs over the
+ * threads, steps outermost inside a block; float32 actions [T,n] in, the outputs the device writes per env-step out — obs
+ * float32 [T,n,4], reward float32 [T,n], terminal uint8 [T,n] (any may be NULL).  No reset: the reference's step() keeps
+ * integrating after `terminal` (mujoco_env.py:157-167). */
+EXPORT void emei_oracle_ip_rollout(int variant, int64_t n, int T, int freq_rate, double dt, double* state, const float* actions,
+                                   float* obs, float* reward, uint8_t* terminal, const oracle_opts_t* opts) {
+    ip_model_t m;
+    emei_oracle_ip_model(&m);
+    ip_ctx_t ctx = {&m, variant};
+    const int64_t BLK = 64, nblk = (n + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t lo = b * BLK, hi = lo + BLK < n ? lo + BLK : n;
+        for (int t = 0; t < T; ++t)
+            for (int64_t i = lo; i < hi; ++i) {
+                double q[2] = {state[4 * i], state[4 * i + 1]}, v[2] = {state[4 * i + 2], state[4 * i + 3]};
+                const double a = (double)actions[(int64_t)t * n + i];
+                oracle_env_step(ip_accel, &ctx, 2, freq_rate, dt, opts, i, q, v, &a);
+                state[4 * i] = q[0], state[4 * i + 1] = q[1], state[4 * i + 2] = v[0], state[4 * i + 3] = v[1];
+                const double o[4] = {q[0], ip_wrap(q[1]), v[0], v[1]};
+                const int64_t row = (int64_t)t * n + i;
+                if (obs) for (int k = 0; k < 4; ++k) obs[4 * row + k] = (float)o[k];
+                if (reward) reward[row] = (float)ip_reward(variant, o);
+                if (terminal) terminal[row] = ip_terminal(&m, variant, o);
+            }
+    }
+}
+
 /* The same smooth dynamics with caller-supplied parameters (cart mass, pole mass, com distance, inertia about
  * the com, gravity), a plain force instead of gear * clipped ctrl and no slider limit: used by the tests to
  * compare the equations of motion with the reference's own SymPy derivation (auxiliary/lagrange_eqs.py). */

@@ -390,6 +390,31 @@ def planar_count_rows(body, state, dt=0.002):
     return out
 
 
+def body_rollout(kind, variant, state, actions, freq_rate, dt, opt=None, reuse=None):
+    """T env-steps of a MuJoCo-backed body in one C call (no Python between steps, no reset): kind "ip" | "dp" | "cheetah" |
+    "hopper"; state [n, dim] float64 (copied), actions float32 [T, n(, nu)] -> dict(state, obs f32 [T,n,dim], reward f32 [T,n],
+    done u8 [T,n]).  Step for step the arithmetic of ip_step / dpend_step / cheetah_step / hopper_step (tests/test_oracle_golden.py);
+    `reuse` = the dict of a previous call of the same shape (its output buffers are written again)."""
+    dim = {"ip": 4, "dp": 6, "cheetah": 18, "hopper": 12}[kind]
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, dim)
+    n = st.shape[0]
+    act = np.ascontiguousarray(actions, dtype=np.float32)
+    T = act.shape[0]
+    if reuse is not None and reuse["obs"].shape == (T, n, dim):
+        obs, rew, dn = reuse["obs"], reuse["reward"], reuse["done"]
+    else:
+        obs, rew, dn = np.empty((T, n, dim), np.float32), np.empty((T, n), np.float32), np.empty((T, n), np.uint8)
+    args = (C.c_int64(n), C.c_int(T), C.c_int(int(freq_rate)), C.c_double(float(dt)), _p(st, C.c_double), _p(act, C.c_float),
+            _p(obs, C.c_float), _p(rew, C.c_float), _p(dn, C.c_uint8), _o(opt))
+    if kind == "ip":
+        lib().emei_oracle_ip_rollout(C.c_int(IP_VARIANTS[variant]), *args)
+    elif kind == "dp":
+        lib().dpend_oracle_rollout(C.c_int(DP_VARIANTS[variant]), *args)
+    else:
+        lib().planar_oracle_rollout(C.c_int(0 if kind == "cheetah" else 1), *args, None)
+    return dict(state=st, obs=obs, reward=rew, done=dn)
+
+
 def xml_constants(model):
     """The oracle's model constants of "ip" | "dp" | "cheetah" | "hopper" in the layout of emei_model_constants."""
     out = np.full(256, np.nan)

@@ -756,6 +756,35 @@ EXPORT void hopper_oracle_is_healthy(int64_t n, const double* obs, uint8_t* out)
     hopper_oracle_is_healthy_p(n, obs, NULL, out, NULL);
 }
 
+/* T env-steps of a planar body in one call (bench.py's cpu_baseline; see emei_oracle_ip_rollout): body 0 = cheetah, 1 = hopper;
+ * state [n, 2 nv] in/out, float32 actions [T,n,nu], outputs obs float32 [T,n,2 nv], reward float32 [T,n], terminal uint8 [T,n]
+ * (any may be NULL); no reset */
+EXPORT void planar_oracle_rollout(int body, int64_t n, int T, int freq_rate, double dt, double* state, const float* actions,
+                                  float* obs, float* reward, uint8_t* terminal, const oracle_opts_t* opts, const double* params) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    m.solver = opts ? opts->solver : ORACLE_SOLVER_NEWTON;
+    const double* P = params ? params : (body == 0 ? kCheetahDefaults : kHopperDefaults);
+    const int nv = m.nv, nu = m.nu, ns = 2 * nv;
+    const int64_t BLK = 16, nblk = (n + BLK - 1) / BLK;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t lo = b * BLK, hi = lo + BLK < n ? lo + BLK : n;
+        for (int t = 0; t < T; ++t)
+            for (int64_t i = lo; i < hi; ++i) {
+                double* s = state + ns * i;
+                double pre[2 * NV], a[NU];
+                memcpy(pre, s, ns * sizeof(double));
+                for (int k = 0; k < nu; ++k) a[k] = (double)actions[((int64_t)t * n + i) * nu + k];
+                oracle_env_step(planar_accel, &m, nv, freq_rate, dt, opts, i, s, s + nv, a);
+                const int64_t row = (int64_t)t * n + i;
+                if (obs) for (int k = 0; k < ns; ++k) obs[ns * row + k] = (float)s[k];
+                if (reward) reward[row] = (float)(body == 0 ? cheetah_reward(s, pre, a, dt * freq_rate, P) : hopper_reward(s, pre, a, dt * freq_rate, P));
+                if (terminal) terminal[row] = body == 0 ? cheetah_terminal(s) : hopper_terminal(s, P);
+            }
+    }
+}
+
 /* diagnostics for the tests: one forward-dynamics evaluation with the Newton solver and what it took — active rows,
  * iterations, final scaled gradient norm — plus, for comparison, the one-sweep acceleration (either output may be NULL) */
 EXPORT void planar_oracle_solve(int body, double dt, double hd, const double* q, const double* v, const double* ctrl, double* acc_newton,

@@ -143,3 +143,39 @@ def test_fused_c_rollout_with_auto_reset_equals_the_per_step_oracle():
         c1 = O.cartpole_rollout_autoreset(variant, s0, acts[:70], 11, ids, max_steps, fr)
         c2 = O.cartpole_rollout_autoreset(variant, c1["state"], acts[70:], 11, ids, max_steps, fr, steps=c1["steps"], episode=c1["episode"])
         assert np.array_equal(c2["state"], b["state"]) and np.array_equal(np.concatenate([c1["done"], c2["done"]]), b["done"])
+
+
+def test_fused_body_rollouts_equal_the_per_step_oracles():
+    """oracle.body_rollout (bench.py's cpu_baseline for the MuJoCo-backed bodies: T env-steps per C call, float32 outputs) against
+    T calls of ip_step / dpend_step / cheetah_step / hopper_step: the float64 state bit for bit, outputs = the rounded ones."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(9)
+    n, T = 150, 10
+    cases = (("ip", "boundary_swingup", 4, 3.0, (), 4, 0.02, "euler", lambda s, a, o: O.ip_step("boundary_swingup", s, a, 4, 0.02, o)),
+             ("ip", "rebound_balancing", 4, 3.0, (), 2, 0.02, "rk4", lambda s, a, o: O.ip_step("rebound_balancing", s, a, 2, 0.02, o)),
+             ("dp", "boundary_swingup", 6, 1.0, (), 2, 0.02, "rk4", lambda s, a, o: O.dpend_step("boundary_swingup", s, a, 2, 0.02, o)),
+             ("cheetah", None, 18, 1.0, (6,), 4, 0.002, "euler", lambda s, a, o: O.cheetah_step(s, a, 4, 0.002, o)),
+             ("hopper", None, 12, 1.0, (3,), 4, 0.002, "rk4", lambda s, a, o: O.hopper_step(s, a, 4, 0.002, o)))
+    for kind, variant, dim, lo, nu, fr, dt, integ, step in cases:
+        s0 = rng.standard_normal((n, dim)) * (0.3 if dim <= 6 else 0.05)
+        if kind == "hopper":
+            s0[:, 1] += 1.25
+        acts = rng.uniform(-lo, lo, (T, n) + nu).astype(np.float32)
+        opt = O.opts(integ)
+        r = O.body_rollout(kind, variant, s0, acts, fr, dt, opt)
+        st = s0.copy()
+        for t in range(T):
+            out = step(st, acts[t].astype(np.float64), opt)
+            st, rew, done = out[0], out[-2], out[-1]
+            assert np.array_equal(rew.astype(np.float32), r["reward"][t]), (kind, t)
+            assert np.array_equal(np.asarray(done).astype(np.uint8), r["done"][t]), (kind, t)
+            if len(out) == 4:  # the pendulums also return the (wrapped) observation
+                assert np.array_equal(out[1].astype(np.float32), r["obs"][t]), (kind, t)
+            else:
+                assert np.array_equal(st.astype(np.float32), r["obs"][t]), (kind, t)
+        assert np.array_equal(st, r["state"]), kind
+        # the output buffers of a previous call are written again
+        r2 = O.body_rollout(kind, variant, s0, acts, fr, dt, opt, reuse=r)
+        assert r2["obs"] is r["obs"] and np.array_equal(r2["state"], st)
+
