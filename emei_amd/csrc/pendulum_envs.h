@@ -340,16 +340,8 @@ struct InvPend {
         static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
         const R dist = (R)m.x_hi - fabs(x_old);
         EMEI_STAT_WAVE(19);  // substeps (waves)
-        // Balancing variants: the hinge's +-90 degree stop (a post-terminal state): the whole wave takes the general two-row
-        // solve (ip_limit_rows handles the slider row too); otherwise the one-row closed form below
-        bool general = false;
-        if constexpr (VARIANT < 2) {
-            static_assert(m.th_lo == -m.th_hi, "symmetric hinge range");
-            general = __ballot(fabs(th_old) > (R)m.th_hi) != 0ull;
-        }
-        if (__builtin_expect(general, 0)) {
-            ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
-        } else if (dist < R(0)) {
+        // The slider row alone, in closed form (the hot path's limit block)
+        auto slider_row = [&]() __attribute__((always_inline)) {
             EMEI_STAT_WAVE(20);  // ... with the limit block
             EMEI_STAT_LANE(21);  // lanes beyond the rail
             const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one
@@ -379,6 +371,20 @@ struct InvPend {
                 a0 = fma_r(A, Jf, a0);
                 a1 = fma_r(-(Q * idet), Jf, a1);
             }
+        };
+        // Balancing variants: the hinge's +-90 degree stop (a post-terminal state).  A wave with such a lane takes a cold,
+        // wave-uniform branch in which THAT lane runs the general two-row solve (ip_limit_rows handles its slider row too) and
+        // every other lane the same closed form as on the hot path: a lane's bits never depend on its wave-mates.
+        bool hinge = false;
+        if constexpr (VARIANT < 2) {
+            static_assert(m.th_lo == -m.th_hi, "symmetric hinge range");
+            hinge = fabs(th_old) > (R)m.th_hi;
+        }
+        if (__builtin_expect(VARIANT < 2 && __ballot(hinge) != 0ull, 0)) {
+            if (hinge) ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
+            else if (dist < R(0)) slider_row();
+        } else if (dist < R(0)) {
+            slider_row();
         }
         s[2] = fma_r(dt, a0, v_old);  // MuJoCo Euler on qvel (no joint damping in this model)
         s[3] = fma_r(dt, a1, om_old);

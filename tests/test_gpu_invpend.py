@@ -238,3 +238,28 @@ def test_hinge_stop_of_the_balancing_variants(variant, integrator):
     eng.step(torch.as_tensor(a1, device=eng.device))
     want = O.ip_step(variant, s1, a1.astype(np.float64), 2, 0.02, O.opts(integrator))[0]
     assert rel_err(eng.get_state().cpu().numpy(), want, floor=1.0) <= 1e-9
+
+
+@pytest.mark.parametrize("variant", ["boundary_balancing", "rebound_balancing"])
+def test_a_lane_at_the_hinge_stop_does_not_change_its_wave_mates(variant):
+    """The staged kernel takes a wave-uniform cold branch when some lane is at the hinge stop; the other lanes must leave it
+    with the bits of the hot path — also those beyond the rail, whose one-row force has a closed form there (pendulum_envs.h:
+    InvPend::substep).  Same wave twice: lane 5 hanging beyond its stop, or upright; every other lane bit for bit."""
+    rng = np.random.default_rng(33)
+    n, T = 64, 48
+    base = np.column_stack([rng.uniform(-2.2, 2.2, n), rng.uniform(-0.2, 0.2, n), rng.normal(0, 2, n), rng.normal(0, 1, n)])
+    assert (np.abs(base[:, 0]) > 2.0).sum() >= 3  # several lanes start beyond the rail (post-terminal for Boundary, rebounding otherwise)
+    acts = torch.as_tensor(rng.uniform(-3, 3, (T, n)).astype(np.float32), device="cuda:0")
+    out = []
+    for theta5 in (0.05, 1.65):
+        s0 = base.copy()
+        s0[5, 1] = theta5
+        eng = _engine(VARIANTS[variant], n, freq_rate=2, real_time_scale=0.02)
+        eng.set_state(s0)
+        obs, rew, done = eng.rollout(acts)
+        out.append((obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), eng.get_state().cpu().numpy()))
+    others = np.arange(n) != 5
+    assert np.abs(out[1][3][5, 1]) > np.pi / 2 - 0.05  # lane 5 really sat at its stop
+    for a, b in zip(out[0], out[1]):
+        a, b = (a[:, others], b[:, others]) if a.shape[0] == T else (a[others], b[others])
+        assert np.array_equal(a, b)
