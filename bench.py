@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 XGMI_LINKS, XGMI_LINK_GBS_BIDIR = 7, 153.6
 XGMI_PEAK_GBS = XGMI_LINKS * XGMI_LINK_GBS_BIDIR / 2
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+MEASURED_NS_PER_F64_INST = 2.0  # tools/op_cost.hip at 4 waves per SIMD, every SIMD busy (profiles/r03_op_cost.txt)
 MULTI_GPU_SHARD = 131072  # BASELINE configs[4]: 1 048 576 envs / 8 GPUs
 
 WORKLOADS = {
@@ -341,8 +342,13 @@ def main():
         # second roofline for the VALU-bound bodies: executed vector instructions per launch (SQ_INSTS_VALU, counted per
         # wave) x 4 cycles of issue each (MI355X_MICROARCH.md: one wave issues a VALU instruction per >= 4 cycles; f64 FMA
         # and f32 alike) / (SIMDs x max clock x kernel time) = the fraction of the chip's vector-issue slots in use
+        # `frac_at_measured_rate`: the same count priced at what this chip's SIMDs actually sustain — 2.0 ns per float64 wave-
+        # instruction per SIMD with 4 resident waves (FMA / mul / add / cvt / cmp alike; in-kernel clock 2.1 GHz; v_rcp_f64 7.1 ns,
+        # float32 / integer 1.2 ns: tools/op_cost.hip, profiles/r03_op_cost.txt)
         out["roofline_valu"] = {"bound": "valu_f64", "valu_insts_per_launch": valu, "cycles_per_inst": 4, "simds": SIMDS,
                                 "clock_ghz": CLOCK_GHZ, "frac": valu * 4 / (SIMDS * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3),
+                                "measured_ns_per_f64_inst": MEASURED_NS_PER_F64_INST,
+                                "frac_at_measured_rate": valu * MEASURED_NS_PER_F64_INST / (SIMDS * kernel_ms * 1e6),
                                 "source": f"{prof.get('profile', 'profiles/')} SQ pass via profiles/traffic.json, NOT measured in this run"}
     # what actually ran: the ranks the process group formed, its backend, every rank's device
     me = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
