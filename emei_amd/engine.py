@@ -190,9 +190,10 @@ class Engine:
                 raise ValueError(f"out: {name} is {tuple(t.shape)} {t.dtype}, expected {shape} {dtype}")
             if not t.is_contiguous():
                 raise ValueError(f"out: {name} must be contiguous")
-        if len(self._out_ok) >= 4096:
-            self._out_ok.clear()
-        self._out_ok[id(out)] = (out, lead)  # holding the tuple keeps its id (and the tensors' shapes) valid
+        if type(out) is tuple:  # a list can have its elements replaced after the check: validated on every call
+            if len(self._out_ok) >= 4096:
+                self._out_ok.clear()
+            self._out_ok[id(out)] = (out, lead)  # holding the tuple keeps its id (and the tensors' shapes) valid
         return out
 
     @_on_device

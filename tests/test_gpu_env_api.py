@@ -149,6 +149,12 @@ def test_output_buffers_are_validated():
     with pytest.raises(ValueError):
         eng.rollout(acts, out=good)  # step-shaped buffers for a 16-step rollout
     eng.rollout(acts, out=eng.alloc_outputs(16))
+    # a list is validated on every call (its elements can be replaced after the first check)
+    lst = list(eng.alloc_outputs(None))
+    eng.step(a, out=lst)
+    lst[0] = obs[:64]
+    with pytest.raises(ValueError):
+        eng.step(a, out=lst)
 
 
 def test_freeze_reset_unfreeze_keeps_the_auto_reset_episodes():
