@@ -5,7 +5,7 @@
 //
 //   using real;  static constexpr int NS (state = qpos ++ qvel), NO (obs), NA (action);
 //   struct Model; make_model(dt, env_params)        // run-time constants, passed by value as a kernel argument
-//   struct Warm; accel(q, v, ctrl, m, hd, qacc, trig, warm)   // forward dynamics incl. soft constraints; `warm` carries the
+//   struct Warm; begin_stages(warm); accel(q, v, ctrl, m, hd, qacc, trig, warm)   // forward dynamics incl. soft constraints; `warm` carries the
 //                                                   // constraint solver's start from one evaluation to the next
 //                                                   // WITHIN an env-step (reset at every step); `hd` = dt when
 //                                                   // joint damping is integrated implicitly (MuJoCo Euler), else 0;
@@ -134,6 +134,7 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
         // + 162 AGPR, 326 spilled SGPRs) while the same source is correct for every other body and for the unrolled
         // form (caught by tests/test_gpu_integrators.py).  The Hopper must NOT: unrolled under its 256-register cap it
         // spills six times the algorithmic bytes to scratch.
+        Body::begin_stages(warm);  // the evaluations of this substep share `warm` (a body may iterate differently then)
         auto stage = [&](int st) __attribute__((always_inline)) {
             Body::accel(qs, vs, ctrl, m, R(0), acc, trig, warm);
             const R b = (st == 0 || st == 3) ? R(1.0 / 6.0) : R(1.0 / 3.0);

@@ -1117,6 +1117,7 @@ struct CheetahBody {
 
     struct WarmNone {};
     using Warm = std::conditional_t<SOLVER == EMEI_SOLVER_SWEEP1, WarmNone, cheetah::NewtonWarm<R>>;
+    __device__ __forceinline__ static void begin_stages(Warm&) {}
     __device__ __forceinline__ static void accel(const R (&q)[cheetah::NV], const R (&v)[cheetah::NV], const R (&ctrl)[NA],
                                                  const Model& m, R hd, R (&qacc)[cheetah::NV], const TrigCtx& trig, Warm& warm) {
         if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) cheetah::accel(q, v, ctrl, m, hd, qacc, trig);

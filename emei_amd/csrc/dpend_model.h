@@ -99,6 +99,7 @@ struct DPendBody {
 
     // q = (x, theta1, theta2), v = (v, omega1, omega2); no joint damping in this model, so `hd` is unused
     struct Warm {};  // a single constraint row: solved exactly in one step
+    __device__ __forceinline__ static void begin_stages(Warm&) {}
     __device__ __forceinline__ static void accel(const R (&q)[3], const R (&v)[3], const R (&ctrl)[NA], const Model& m, R,
                                                  R (&qacc)[3], const TrigCtx& trig, Warm&) {
         const R phi1 = q[1] + (R)m.phi_off, phi2 = phi1 + q[2];

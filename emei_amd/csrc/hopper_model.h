@@ -377,6 +377,7 @@ template <typename R>
 struct NewtonWarm {
     R a[NV];
     bool valid;
+    bool stages;  // RK4: the four stage evaluations of a substep share this object (body_kernels.h: begin_stages)
 };
 template <typename R>
 __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
@@ -505,6 +506,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             sym_matvec(A, a, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gr[i] -= f[i];
+            uint32_t flags = 0;  // the active set this pass assembles: bit k = limit row k, bits 3 + 3 pt .. = the point's edges (s1, s2, sy)
             auto limit = [&](auto kc) __attribute__((always_inline)) {  // theta_k = phi_P - phi_C: J = +-(e_P - e_C)
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
@@ -519,6 +521,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
                     const R x = J * (a[P] - a[C]) - aref;
                     if (x < R(0)) {
+                        flags |= 1u << k;
                         const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);
                         const R t = Dw * x * J;
                         gr[P] += t, gr[C] -= t;
@@ -560,6 +563,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
                     const R x1 = xn + xt, x2 = xn - xt;
                     const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
+                    flags |= ((s1 ? 1u : 0u) | (s2 ? 2u : 0u) | (sy ? 4u : 0u)) << (3 + 3 * pt);
                     if (s1 | s2 | sy) {
                         const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c)) * (R)kLinkInvWeight0[LNK]);
                         const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
@@ -593,6 +597,60 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             ldl_backward(A, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= gr[i];
+            // The cost is piecewise quadratic: the step just taken IS the minimiser of the piece it was assembled on, so if the
+            // active set at the new iterate is the same one, the iteration is over — found with the rows' residuals alone
+            // (~20 instructions per row block) instead of a whole further pass whose gradient test would say the same (the
+            // iterate is not touched: results are bit-identical; a set that flips on a rounding boundary goes on to that pass).
+            // In the RK4 kernels only (`stages` is a compile-time constant after inlining): A/B on one box 25.85 -> 24.80 ms per 100
+            // RK4 steps (86 % of the warm-started lanes take one step and then only verify); in the Euler kernel, where every
+            // evaluation starts cold, the sweep costs what it saves (8.035 -> 8.08 ms).
+            if (!warm.stages) continue;
+            uint32_t again = 0;
+            auto limit2 = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
+                if (rows & (1u << k)) {
+                    const R th = q[3 + k], vk = v[3 + k];
+                    const bool lower = th < (R)kGeom.lo[k];
+                    const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
+                    const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
+                    const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
+                    again |= (J * (a[P] - a[C]) - aref < R(0)) ? (1u << k) : 0u;
+                }
+            };
+            limit2(std::integral_constant<int, 0>{}), limit2(std::integral_constant<int, 1>{}), limit2(std::integral_constant<int, 2>{});
+            auto contact2 = [&](auto pt_c) __attribute__((always_inline)) {
+                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+                if (rows & (1u << (3 + pt))) {
+                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
+                    const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
+                    R Jx[NV], Jz[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
+                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    Jx[LNK] = r.z, Jz[LNK] = -r.x;
+#pragma unroll
+                    for (int b = LNK + 1; b < NL; ++b) Jx[b] = D[b].z, Jz[b] = -D[b].x;
+                    R vn = R(0), vt = R(0), an = R(0), at = R(0);
+#pragma unroll
+                    for (int i = LNK; i < NV; ++i) {
+                        vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
+                        an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
+                    }
+                    const R mu = (R)kGeom.friction[gi];
+                    const R pos = dist - (R)kGeom.margin;
+                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
+                    again |= ((xn + xt < R(0) ? 1u : 0u) | (xn - xt < R(0) ? 2u : 0u) | (xn < R(0) ? 4u : 0u)) << (3 + 3 * pt);
+                }
+            };
+            contact2(integral_constant<int, 0>{}), contact2(integral_constant<int, 1>{}), contact2(integral_constant<int, 2>{});
+            contact2(integral_constant<int, 3>{}), contact2(integral_constant<int, 4>{}), contact2(integral_constant<int, 5>{});
+            contact2(integral_constant<int, 6>{}), contact2(integral_constant<int, 7>{});
+            if (again == flags) {
+                converged = true;
+                break;
+            }
         }
         EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
         report_cap_hit(trig, !converged);
@@ -649,6 +707,9 @@ struct HopperBody {
 
     struct WarmNone {};
     using Warm = std::conditional_t<SOLVER == EMEI_SOLVER_SWEEP1, WarmNone, hopper::NewtonWarm<R>>;
+    __device__ __forceinline__ static void begin_stages(Warm& w) {
+        if constexpr (SOLVER != EMEI_SOLVER_SWEEP1) w.stages = true;
+    }
     __device__ __forceinline__ static void accel(const R (&q)[6], const R (&v)[6], const R (&ctrl)[NA], const Model& m, R hd,
                                                  R (&qacc)[6], const TrigCtx& trig, Warm& warm) {
         if constexpr (SOLVER == EMEI_SOLVER_SWEEP1) hopper::accel(q, v, ctrl, m, hd, qacc, trig);

@@ -70,6 +70,7 @@ struct InvPendBody {
 
     // q = (x, theta), v = (xdot, omega); no joint damping in this model (`hd` unused)
     struct Warm {};  // a single constraint row: solved exactly in one step
+    __device__ __forceinline__ static void begin_stages(Warm&) {}
     __device__ __forceinline__ static void accel(const R (&q)[2], const R (&v)[2], const R (&ctrl)[NA], const Model& m, R,
                                                  R (&qacc)[2], const TrigCtx& trig, Warm&) {
         R sn, cs;
