@@ -114,7 +114,8 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
     if constexpr (!RK4) {
         // Euler: every evaluation starts cold.  A/B on one box (config 4 / Hopper): 10.1 vs 10.9 ms and 8.0 vs 8.2 ms per
         // 100 steps — the previous substep's minimiser is no nearer to the new one than the unconstrained acceleration
-        // is (either way a lane needs one step and the pass that confirms it), and carrying it costs registers.  The RK4
+        // is (either way a lane needs one step and the pass that confirms it), and carrying it costs registers (round 3, with the
+        // Hopper's verify sweep switched on for it: 8.00 vs 8.52 ms; config 4: 8.05 vs 8.16).  The RK4
         // stages below DO share it: 25.6 vs 28.9 ms (Hopper), 37.3 vs 41.4 ms (cheetah); resetting it per substep loses half
         // of that (27.6 / 39.8).
         typename Body::Warm cold{};
