@@ -32,3 +32,31 @@ def test_parent_never_imports_torch_before_launching():
     assert main.index("self_launch(a.gpus)") < main.index("import torch")
     body = src[src.index("def self_launch("):src.index("def main():")]
     assert "import torch" not in body and "torch.cuda" not in body
+
+
+def test_host_cpu_share_is_capped_by_the_cgroup_quota(monkeypatch):
+    """bench.host_cpu_share(): the affinity mask capped by cpu.max (cgroup v2) — a one-GPU box shows 256 CPUs and grants 16."""
+    import builtins
+    import io
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    real_open = builtins.open
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+
+    def fake(quota):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                return io.StringIO(quota)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise OSError("no cgroup v1 here")
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.host_cpu_share() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.host_cpu_share() == 256
+    monkeypatch.setattr(builtins, "open", fake("150000 100000\n"))  # 1.5 CPUs -> 2 threads
+    assert bench.host_cpu_share() == 2
