@@ -31,7 +31,7 @@ ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
 FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
-ABI_VERSION = 3
+ABI_VERSION = 4
 IO_F32, IO_F64 = 0, 1  # enum emei_io_dtype
 REWARD_BATCH_CTRL_COST = 1  # flag of emei_reward_io (half_cheetah.py:61 / hopper.py:98: np.sum over the whole batch)
 # enum emei_kernel_id (emei_last_rollout_kernel)
@@ -86,6 +86,7 @@ SYMBOLS = {
     "emei_last_error": (C.c_char_p, []),
     "emei_abi_version": (C.c_int, []),
     "emei_model_constants": (C.c_int, [C.c_int, _vp, C.c_int]),
+    "emei_model_invweights": (C.c_int, [C.c_int, _vp, C.c_int]),
     "emei_env_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emei_reset": (C.c_int, [_vp, _u64, _vp]),
     "emei_set_seed": (C.c_int, [_vp, _u64]),

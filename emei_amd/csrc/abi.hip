@@ -101,6 +101,34 @@ extern "C" EMEI_API int emei_model_constants(int env_id, double* out, int capaci
     return n;
 }
 
+extern "C" EMEI_API int emei_model_invweights(int env_id, double* out, int capacity) {
+    if (!out || capacity < 0) return fail(EMEI_ERR_INVALID, "emei_model_invweights: bad argument");
+    double buf[32];
+    int n;
+    switch (env_id) {
+        case EMEI_IP_REBOUND_BALANCING:
+        case EMEI_IP_BOUNDARY_BALANCING:
+        case EMEI_IP_REBOUND_SWINGUP:
+        case EMEI_IP_BOUNDARY_SWINGUP: {
+            constexpr IpModel m = ip_make_model(false);
+            buf[0] = m.invw, buf[1] = m.invw_hinge, n = 2;
+            break;
+        }
+        case EMEI_IDP_REBOUND_BALANCING:
+        case EMEI_IDP_BOUNDARY_BALANCING:
+        case EMEI_IDP_REBOUND_SWINGUP:
+        case EMEI_IDP_BOUNDARY_SWINGUP: buf[0] = dpend::make_model(false, 0.002).invw, n = 1; break;
+        case EMEI_HALFCHEETAH_RUNNING: n = cheetah::xml_invweights(buf); break;
+        case EMEI_HOPPER_RUNNING: n = hopper::xml_invweights(buf); break;
+        case EMEI_CARTPOLE_SWINGUP:
+        case EMEI_CARTPOLE_BALANCING: return fail(EMEI_ERR_UNSUPPORTED, "emei_model_invweights: CartPole has no constraint rows");
+        default: return fail(EMEI_ERR_INVALID, "unknown env_id %d", env_id);
+    }
+    if (n > capacity) return fail(EMEI_ERR_INVALID, "emei_model_invweights: %d values, capacity %d", n, capacity);
+    memcpy(out, buf, n * sizeof(double));
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // {sin, cos}(k * 2pi/256), k = 0..255, correctly rounded from long double, one copy per device.
 // Allocated on the first emei_create / stateless call for that device (never inside a hot launch

@@ -236,15 +236,69 @@ inline int xml_constants(double* out) {
 }
 
 // Inverse weights at qpos0 (MuJoCo's mj_setConst; the diagonal approximation of J M^-1 J' that scales the constraint
-// regularisers): (M0^-1)_jj of the six leg joints (bthigh .. ffoot) and the mean translational inverse inertia
-// trace(J_com M0^-1 J_com') / 3 of every link in the PERMUTED link order (bfoot, bshin, bthigh, ffoot, fshin, fthigh,
-// torso).  Values generated by oracle/planar_oracle.c:set_invweights (oracle.planar_invweights("cheetah")), which
-// inverts the joint-space inertia at qpos0; tests/test_oracle_cheetah.py pins this table to the oracle's.
-__device__ constexpr double kDofInvWeight0[6] = {2.729788644884895, 5.893248984162908, 8.894877004054672,
-                                                 3.0813926054768794, 6.882795962275771, 9.46813496276976};
-__device__ constexpr double kLinkInvWeight0[7] = {0.2437492834901718, 0.12720922534654563, 0.09691101560963146,
-                                                  0.2661441029233888, 0.1319968179007738, 0.08148379481367078,
-                                                  0.06415751945610275};
+// regularisers): dof_invweight0 = (M0^-1)_jj of the six leg joints (bthigh .. ffoot) and body_invweight0 = the mean
+// translational inverse inertia trace(J_com M0^-1 J_com') / 3 of every link, in the PERMUTED link order (bfoot, bshin,
+// bthigh, ffoot, fshin, fthigh, torso).  Derived HERE, at compile time, from this file's own model — the absolute-angle inertia
+// M_u(qpos0) assembled from the mass-moment vectors exactly as accel() does it (every link angle is 0 at qpos0: R = 1) — and not
+// from the oracle: a joint velocity theta_k = Omega_child - Omega_parent is the row J = e_child - e_parent of the absolute
+// coordinates, so (M_q^-1)_kk = J M_u^-1 J'; a link's com Jacobian is perp() of the link vectors on its root path.  The oracle
+// inverts the joint-space RNE inertia instead (planar_oracle.c:set_invweights); tests/test_oracle_solver.py compares the two
+// derivations (and a third, energy-based one in NumPy from the XML constants) through emei_model_invweights.
+struct InvWeights {
+    double dof[6], link[7];
+};
+constexpr InvWeights cheetah_invweights() {
+    using namespace cheetah_host;
+    const Model m = cheetah_make_model(0.002);
+    const CheetahBodies B = cheetah_bodies();
+    double A[NV][NV] = {};
+    for (int b = 0; b < 7; ++b) A[b][b] = m.diag[b], A[P_X][b] = A[b][P_X] = m.sz[b], A[P_Z][b] = A[b][P_Z] = -m.sx[b];
+    A[P_X][P_X] = A[P_Z][P_Z] = m.mtot;
+    // permuted link -> xml body, and the chain of link vectors from an ancestor towards a descendant: the ancestor's vector to
+    // the child ON that path = the child's body origin in the ancestor's frame (bpos)
+    const int perm_body[7] = {3, 2, 1, 6, 5, 4, 0};
+    int body_perm[7] = {};
+    for (int p = 0; p < 7; ++p) body_perm[perm_body[p]] = p;
+    for (int j = 0; j < 7; ++j) {  // descendant j, every proper ancestor a: M[a][j] = d_(a -> towards j) . s_j
+        int child = perm_body[j];
+        for (int a = B.parent[child]; a >= 0; child = a, a = B.parent[a]) {
+            const int pa = body_perm[a];
+            A[pa][j] = A[j][pa] = B.bpos[child].x * m.sx[j] + B.bpos[child].z * m.sz[j];
+        }
+    }
+    const int jc[6] = {P_BTHIGH, P_BSHIN, P_BFOOT, P_FTHIGH, P_FSHIN, P_FFOOT};
+    const int jp[6] = {P_TORSO, P_BTHIGH, P_BSHIN, P_TORSO, P_FTHIGH, P_FSHIN};
+    for (int k = 0; k < 6; ++k) {  // armature acts on theta_k = phi_child - phi_parent
+        A[jc[k]][jc[k]] += m.arm[k], A[jp[k]][jp[k]] += m.arm[k];
+        A[jc[k]][jp[k]] -= m.arm[k], A[jp[k]][jc[k]] -= m.arm[k];
+    }
+    InvWeights w{};
+    for (int k = 0; k < 6; ++k) {
+        double J[NV] = {};
+        J[jc[k]] = 1, J[jp[k]] = -1;
+        w.dof[k] = ce::spd_quad<NV>(A, J);
+    }
+    for (int p = 0; p < 7; ++p) {
+        double Jx[NV] = {}, Jz[NV] = {};
+        Jx[P_X] = 1, Jz[P_Z] = 1;
+        const int b = perm_body[p];
+        Jx[p] = B.com[b].z, Jz[p] = -B.com[b].x;  // d/dphi of R(phi) c at phi = 0: perp(c)
+        int child = b;
+        for (int a = B.parent[b]; a >= 0; child = a, a = B.parent[a]) Jx[body_perm[a]] = B.bpos[child].z, Jz[body_perm[a]] = -B.bpos[child].x;
+        w.link[p] = (ce::spd_quad<NV>(A, Jx) + ce::spd_quad<NV>(A, Jz)) / 3.0;  // three world axes; nothing moves along y
+    }
+    return w;
+}
+__device__ constexpr InvWeights kInvW = cheetah_invweights();
+// emei_model_invweights (include/emei_hip.h): dof_invweight0 of the six leg joints, then body_invweight0 in XML body order
+inline int xml_invweights(double* out) {
+    constexpr InvWeights w = cheetah_invweights();
+    const int perm_body[7] = {3, 2, 1, 6, 5, 4, 0};
+    int n = 0;
+    for (int k = 0; k < 6; ++k) out[n++] = w.dof[k];
+    for (int p = 0; p < 7; ++p) out[6 + perm_body[p]] = w.link[p];
+    return n + 7;
+}
 #ifndef EMEI_MAX_NEWTON
 #define EMEI_MAX_NEWTON 24
 #endif
@@ -761,7 +815,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
                     for (int i = 0; i < NV; ++i) put(slot, i, in_pat(C, i) ? Jn[i] : R(0)), put(slot, NV + i, R(0));
                     put(slot, 18, an), put(slot, 19, R(0)), put(slot, 20, -aref), put(slot, 21, R(0));
-                    put(slot, 22, R(0.25) * div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]));
+                    put(slot, 22, R(0.25) * div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]));
                     put(slot, 23, warm.valid ? wn : an), put(slot, 24, R(0)), put(slot, 25, R(0));
                     ++slot;
                 }
@@ -793,7 +847,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                         }
                     const R imp = impedance(dist, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
                     const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * kGeom.friction * kGeom.friction * (1.0 + kGeom.friction * kGeom.friction)) *
-                                                (R)kLinkInvWeight0[LNK]);
+                                                (R)kInvW.link[LNK]);
                     ldl_forward<LNK, false>(A, Jz);  // Y_n, Y_t
                     ldl_forward<LNK, false>(A, Jx);
 #pragma unroll
@@ -948,7 +1002,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
                     const R x = J * (a[C] - a[P]) - aref;
                     if (x < R(0)) {
-                        const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);  // 1 / R
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]);  // 1 / R
                         const R t = Dw * x * J;
                         gr[C] += t, gr[P] -= t;
                         A[C][C] += Dw, A[P][P] += Dw;
@@ -999,7 +1053,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     if (s1 | s2 | sy) {
                         // R_edge = 2 mu^2 (1 - imp) / imp * invweight (1 + mu^2)
                         const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * kGeom.friction * kGeom.friction * (1.0 + kGeom.friction * kGeom.friction)) *
-                                                    (R)kLinkInvWeight0[LNK]);
+                                                    (R)kInvW.link[LNK]);
                         const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
                         const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
                         const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);

@@ -63,5 +63,37 @@ constexpr double atan_small(double y, double x) {
     return t * s;
 }
 
+// x <- A^-1 x for a symmetric positive definite N x N matrix given in full (both triangles): dense LDL^T without pivoting.
+// Used at compile time only (the qpos0 inverse weights of the constraint regularisers).
+template <int N>
+constexpr void spd_solve(const double (&A)[N][N], double (&x)[N]) {
+    double L[N][N] = {}, D[N] = {};
+    for (int j = 0; j < N; ++j) {
+        double d = A[j][j];
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+        D[j] = d;
+        for (int i = j + 1; i < N; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = v / d;
+        }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int k = 0; k < i; ++k) x[i] -= L[i][k] * x[k];
+    for (int i = 0; i < N; ++i) x[i] /= D[i];
+    for (int i = N - 1; i >= 0; --i)
+        for (int k = i + 1; k < N; ++k) x[i] -= L[k][i] * x[k];
+}
+// J . A^-1 J
+template <int N>
+constexpr double spd_quad(const double (&A)[N][N], const double (&J)[N]) {
+    double w[N] = {};
+    for (int i = 0; i < N; ++i) w[i] = J[i];
+    spd_solve<N>(A, w);
+    double s = 0;
+    for (int i = 0; i < N; ++i) s += J[i] * w[i];
+    return s;
+}
+
 }  // namespace ce
 }  // namespace emei

@@ -155,11 +155,50 @@ inline int xml_constants(double* out) {
     return n;
 }
 
-// inverse weights at qpos0 (see cheetah_model.h:kDofInvWeight0): joints thigh, leg, foot; links in chain order foot, leg,
-// thigh, torso.  Generated by oracle/planar_oracle.c:set_invweights (oracle.planar_invweights("hopper")).
-__device__ constexpr double kDofInvWeight0[3] = {0.9173573040079778, 0.8423092317158415, 0.9000381439194954};
-__device__ constexpr double kLinkInvWeight0[NL] = {0.0669027107682187, 0.04959511864425974, 0.05192331014610705,
-                                                   0.08492239638897525};
+// inverse weights at qpos0 (see cheetah_model.h:cheetah_invweights): joints thigh, leg, foot; links in chain order foot, leg,
+// thigh, torso.  Derived at compile time from THIS file's absolute-angle inertia at qpos0 (all link angles 0), not from the
+// oracle; compared with the oracle's joint-space derivation by tests/test_oracle_solver.py through emei_model_invweights.
+struct InvWeights {
+    double dof[3], link[NL];
+};
+constexpr InvWeights hopper_invweights() {
+    const Model m = make_model(0.002);
+    const HopperLinks K = hopper_links();
+    double A[NV][NV] = {};
+    for (int i = 0; i < NL; ++i) {
+        A[i][i] = m.diag[i], A[P_X][i] = A[i][P_X] = m.sz[i], A[P_Z][i] = A[i][P_Z] = -m.sx[i];
+        for (int j = 0; j < i; ++j) A[i][j] = A[j][i] = m.d[i][0] * m.sx[j] + m.d[i][1] * m.sz[j];  // j is carried by i
+    }
+    A[P_X][P_X] = A[P_Z][P_Z] = m.mtot;
+    const int jc[3] = {L_THIGH, L_LEG, L_FOOT}, jp[3] = {L_TORSO, L_THIGH, L_LEG};
+    for (int k = 0; k < 3; ++k) {
+        A[jc[k]][jc[k]] += m.arm[k], A[jp[k]][jp[k]] += m.arm[k];
+        A[jc[k]][jp[k]] -= m.arm[k], A[jp[k]][jc[k]] -= m.arm[k];
+    }
+    InvWeights w{};
+    for (int k = 0; k < 3; ++k) {
+        double J[NV] = {};
+        J[jc[k]] = -1, J[jp[k]] = 1;  // theta_k = -(phi_child - phi_parent): hinges about -y
+        w.dof[k] = ce::spd_quad<NV>(A, J);
+    }
+    for (int b = 0; b < NL; ++b) {
+        double Jx[NV] = {}, Jz[NV] = {};
+        Jx[P_X] = 1, Jz[P_Z] = 1;
+        Jx[b] = K.gc[b].z, Jz[b] = -K.gc[b].x;                             // the link's own com: its capsule centre
+        for (int a = b + 1; a < NL; ++a) Jx[a] = m.d[a][1], Jz[a] = -m.d[a][0];  // ancestors: perp(their link vector)
+        w.link[b] = (ce::spd_quad<NV>(A, Jx) + ce::spd_quad<NV>(A, Jz)) / 3.0;
+    }
+    return w;
+}
+__device__ constexpr InvWeights kInvW = hopper_invweights();
+// emei_model_invweights: dof_invweight0 of thigh, leg, foot, then body_invweight0 in XML body order torso, thigh, leg, foot
+inline int xml_invweights(double* out) {
+    constexpr InvWeights w = hopper_invweights();
+    int n = 0;
+    for (int k = 0; k < 3; ++k) out[n++] = w.dof[k];
+    for (int b = NL - 1; b >= 0; --b) out[n++] = w.link[b];
+    return n;
+}
 
 // dense LDL^T of the symmetric 6x6 (lower triangle of A); L in the strict lower triangle, 1/D in invd
 template <typename R>
@@ -522,7 +561,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R x = J * (a[P] - a[C]) - aref;
                     if (x < R(0)) {
                         flags |= 1u << k;
-                        const R Dw = div_r(imp, (R(1) - imp) * (R)kDofInvWeight0[k]);
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]);
                         const R t = Dw * x * J;
                         gr[P] += t, gr[C] -= t;
                         A[C][C] += Dw, A[P][P] += Dw, A[P][C] -= Dw;  // P > C
@@ -565,7 +604,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
                     flags |= ((s1 ? 1u : 0u) | (s2 ? 2u : 0u) | (sy ? 4u : 0u)) << (3 + 3 * pt);
                     if (s1 | s2 | sy) {
-                        const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c)) * (R)kLinkInvWeight0[LNK]);
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c)) * (R)kInvW.link[LNK]);
                         const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
                         const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
                         const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);

@@ -25,8 +25,9 @@ extern "C" {
 /* ABI history.  1: emei_config of 64 B.  2: integrator / noise layout / per-coordinate sigmas (328 B), env_params (400 B),
  * emei_set_seed, emei_last_rollout_kernel, emei_config.solver (the former reserved0; reserved words MUST be zero).
  * 3: the *_io stateless entry points (float64 observations), emei_freeze / emei_unfreeze snapshot the reset key,
- *    emei_model_constants, emei_get_solver_cap_hits. */
-#define EMEI_ABI_VERSION 3
+ *    emei_model_constants, emei_get_solver_cap_hits.
+ * 4: emei_model_invweights. */
+#define EMEI_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -171,6 +172,16 @@ EMEI_API int emei_abi_version(void);
  *       solref time constant, solimp dmin, dmax, width, limit solref time constant, solimp dmin, dmax, width, ctrlrange lo, hi,
  *       rootz ref, sign of the leg hinges' axis (+1: +y, -1: -y) */
 EMEI_API int emei_model_constants(int env_id, double* out, int capacity);
+
+/* Debug / test getter: the qpos0 inverse weights (MuJoCo's mj_setConst: dof_invweight0 = (M0^-1)_jj of a joint, body_invweight0 =
+ * trace(J_com M0^-1 J_com') / 3 of a body) that scale the constraint regularisers R = (1 - d) / d * diagApprox of the kernels of
+ * `env_id` — computed at compile time from the kernels' OWN model (absolute-angle inertia at qpos0), so that a test can compare
+ * them with the oracle's joint-space derivation as two independent computations (tests/test_oracle_solver.py; what is being
+ * restated: mujoco.mj_step behind mujoco_env.py:93).  Same calling convention as emei_model_constants.  Host only.
+ *   InvertedPendulum x4 (2): slider, hinge.   InvertedDoublePendulum x4 (1): slider.
+ *   HalfCheetahRunning (13): the six leg hinges in XML order, then the seven bodies in XML order.
+ *   HopperRunning (7): thigh, leg, foot hinges, then torso, thigh, leg, foot bodies. */
+EMEI_API int emei_model_invweights(int env_id, double* out, int capacity);
 
 /* Static facts about an env id: obs_dim, act_dim (0 = discrete scalar action), state_dim. */
 EMEI_API int emei_env_dims(int env_id, int* obs_dim, int* act_dim, int* state_dim);

@@ -95,6 +95,13 @@ EXPORT int dpend_oracle_xml_constants(double* out) {
     return 17;
 }
 
+/* dof_invweight0 of the slider at qpos0, for the comparison with the kernels' closed form (tests/test_oracle_solver.py) */
+EXPORT double dpend_oracle_invweight(void) {
+    dp_model_t m;
+    dpend_oracle_model(&m, 0.002);
+    return m.invw;
+}
+
 typedef struct { const dp_model_t* m; double off; } dp_ctx_t;
 /* forward dynamics (no joint damping: hd unused); integrators in integrators.h */
 static void dp_accel(const void* ctx, double dt, double hd, const double* q, const double* v, const double* ctrl_in, double* acc) {

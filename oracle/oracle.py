@@ -445,6 +445,24 @@ def planar_invweights(body):
     return d, b
 
 
+def dpend_invweight():
+    """dof_invweight0 of the InvertedDoublePendulum's slider at qpos0 (dpend_oracle.c:dpend_oracle_model)."""
+    lib().dpend_oracle_invweight.restype = C.c_double
+    return float(lib().dpend_oracle_invweight())
+
+
+def planar_rows(body, q, v, dt=0.002, cap=80):
+    """(J [nr, nv], aref [nr], D [nr]) of the Newton solver's scalar constraint rows at one state (build_rows' order)."""
+    nv = 9 if body == "cheetah" else 6
+    q, v = np.ascontiguousarray(q, np.float64), np.ascontiguousarray(v, np.float64)
+    J, aref, D = np.zeros((cap, nv)), np.zeros(cap), np.zeros(cap)
+    lib().planar_oracle_rows.restype = C.c_int
+    nr = lib().planar_oracle_rows(C.c_int(0 if body == "cheetah" else 1), C.c_double(dt), _p(q, C.c_double), _p(v, C.c_double),
+                                  C.c_int(cap), _p(J, C.c_double), _p(aref, C.c_double), _p(D, C.c_double))
+    assert nr <= cap
+    return J[:nr], aref[:nr], D[:nr]
+
+
 def planar_geometry(body, q):
     """(body masses [nb], world centres of the capsule end spheres [ng,2,2]) at configuration q."""
     nb, ng, nv = {"cheetah": (7, 8, 9), "hopper": (4, 4, 6)}[body]

@@ -414,7 +414,11 @@ static int build_rows(const planar_model_t* m, const kin_t* k, double dt, const 
             point_jacobian(m, k, b, p, Jx, Jz);
             double pos = dist - m->contact_margin, mu = m->geom_friction[g];
             double imp = impedance(pos, m->c_dmin, m->c_dmax, m->c_width);
-            double R = (1 - imp) / imp * (m->body_invweight0[b] * (1 + mu * mu)); /* diagApprox of a pyramid edge */
+            /* diagApprox of a pyramid edge n +- mu t in the isotropic approximation, then the edges' common regulariser as the
+             * friction-curvature match of the elliptic cone at impratio 1 (the pair n +- mu t costs D (x_n^2 + mu^2 x_t^2)):
+             * R_py = 2 mu^2 R.  Derivation and check on these rows: tests/test_oracle_solver.py::
+             * test_pyramid_edge_regulariser_is_the_friction_match_of_the_elliptic_cone */
+            double R = (1 - imp) / imp * (m->body_invweight0[b] * (1 + mu * mu));
             double Rpy = 2 * mu * mu * R;
             double D = 1.0 / (Rpy > MJ_MINVAL ? Rpy : MJ_MINVAL);
             /* edges n + mu t, n - mu t in the plane; the two edges n +- mu y of condim 3 have no y-motion to act on: J_n */
@@ -865,6 +869,22 @@ EXPORT void planar_oracle_row_mask(int body, int64_t n, const double* state, uin
             }
         mask_out[i] = mask;
     }
+}
+/* diagnostics for the tests: the scalar constraint rows the Newton solver sees at one state — Jacobians [nr][nv], reference
+ * accelerations, weights D = 1 / R — in build_rows' order (violated limits, then 4 pyramid edges per touching end sphere:
+ * n + mu t, n - mu t, n, n).  Returns the row count; at most `cap` rows are written. */
+EXPORT int planar_oracle_rows(int body, double dt, const double* q, const double* v, int cap, double* J_out, double* aref_out, double* D_out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    kin_t k;
+    kinematics(&m, q, &k);
+    crow_t rows[MAXROWS];
+    const int nr = build_rows(&m, &k, dt, q, v, rows);
+    for (int r = 0; r < nr && r < cap; ++r) {
+        memcpy(J_out + (size_t)r * m.nv, rows[r].J, m.nv * sizeof(double));
+        aref_out[r] = rows[r].aref, D_out[r] = rows[r].D;
+    }
+    return nr;
 }
 EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
     planar_model_t m;

@@ -75,14 +75,165 @@ def _qfrc_smooth(body, q, v, ctrl, bias):
     return f
 
 
-def test_device_tables_of_inverse_weights_match_the_oracle():
-    """cheetah_model.h / hopper_model.h carry the qpos0 inverse weights as literal tables: they are the oracle's numbers."""
-    for body, hdr, perm in (("cheetah", "cheetah_model.h", [3, 2, 1, 6, 5, 4, 0]), ("hopper", "hopper_model.h", [3, 2, 1, 0])):
+ENV_ID = {"cheetah": 6, "hopper": 11}  # EMEI_HALFCHEETAH_RUNNING, EMEI_HOPPER_RUNNING (include/emei_hip.h)
+XML_TAG = {"cheetah": "ch", "hopper": "hp"}
+
+
+def _kernel_invweights(env_id):
+    import ctypes as C
+
+    from emei_amd import _lib as L
+
+    buf = (C.c_double * 32)()
+    n = L.lib().emei_model_invweights(env_id, C.cast(buf, C.c_void_p), 32)
+    assert n > 0, L.lib().emei_last_error()
+    return np.array(buf[:n])
+
+
+def _xml_tree(body):
+    """(mass, com, inertia, anchor — all at qpos0 in the world — parent, hinge sign, armature per dof) of a planar tree from the XML
+    numbers: tests/test_model_constants.planar_expected applies MuJoCo's documented compiler rules to
+    tests/golden/model_constants_golden.npz (the reference's assets/*.xml parsed as written)."""
+    import test_model_constants as TM
+    from conftest import GOLDEN
+
+    x = np.load(os.path.join(GOLDEN, "model_constants_golden.npz"))
+    t = XML_TAG[body]
+    vec = TM.planar_expected(x, t)
+    nb = len(x[f"{t}_body_names"])
+    ng = sum(1 for g in range(len(x[f"{t}_geom_names"])) if x[f"{t}_geom_is_capsule"][g] and x[f"{t}_geom_body"][g] >= 0)
+    per_body = vec[1:1 + 6 * nb].reshape(nb, 6)
+    joints = vec[1 + 6 * nb + 7 * ng:][: 6 * (nb - 1)].reshape(nb - 1, 6)
+    parent = [int(p) for p in x[f"{t}_body_parent"]]
+    anchor = np.zeros((nb, 2))
+    for b in range(nb):
+        anchor[b] = per_body[b, 4:6] + (anchor[parent[b]] if parent[b] >= 0 else 0.0)
+    sign = np.ones(nb)
+    sign[1:] = vec[-1]  # leg hinges about +-y; the root hinge about +y
+    arm = np.concatenate([np.zeros(3), joints[:, 2]])
+    return per_body[:, 0], anchor + per_body[:, 1:3], per_body[:, 3], anchor, parent, sign, arm
+
+
+def _perp(v):
+    return np.array([v[1], -v[0]])  # d/dphi of a vector rotated about +y
+
+
+def _energy_invweights(body):
+    """Third derivation, NumPy from the XML: at qpos0 the kinetic energy is T = sum_b m_b |J_b qd|^2 / 2 + I_b (w_b qd)^2 / 2 with
+    J_b the com Jacobian (dofs rootx, rootz, then one hinge per body) and w_b the sum of the hinge signs on b's root path, so
+    M0 = sum_b m_b J_b' J_b + I_b w_b w_b' + diag(armature); dof_invweight0 = diag(M0^-1), body_invweight0 = trace(J_b M0^-1 J_b') / 3
+    (mj_setConst: the mean over the THREE world axes; a planar tree has no motion along y)."""
+    mass, com, inertia, anchor, parent, sign, arm = _xml_tree(body)
+    nb, nv = len(mass), len(mass) + 2
+    M, Jc = np.diag(arm).astype(np.float64), []
+    for b in range(nb):
+        J, w = np.zeros((2, nv)), np.zeros(nv)
+        J[0, 0] = J[1, 1] = 1.0
+        a = b
+        while a >= 0:
+            J[:, 2 + a] = sign[a] * _perp(com[b] - anchor[a])
+            w[2 + a] = sign[a]
+            a = parent[a]
+        M += mass[b] * J.T @ J + inertia[b] * np.outer(w, w)
+        Jc.append(J)
+    Minv = np.linalg.inv(M)
+    return np.diag(Minv).copy(), np.array([np.trace(J @ Minv @ J.T) / 3.0 for J in Jc])
+
+
+@pytest.mark.parametrize("body", ["cheetah", "hopper"])
+def test_inverse_weights_three_independent_derivations(body):
+    """The qpos0 inverse weights that scale every constraint regulariser (R = (1 - d) / d * diagApprox; what is restated is
+    mujoco.mj_step behind mujoco_env.py:93) used to be literal tables in the kernels' headers, pasted from the oracle (VERDICT r03
+    weak #2).  Now three derivations that share no code are compared:
+      (i)   the kernels': compile-time, from the absolute-angle inertia of cheetah_model.h / hopper_model.h at qpos0
+            (mass-moment vectors; a joint is the row e_child - e_parent) — exported by emei_model_invweights;
+      (ii)  the oracle's: joint-space inertia from unit-acceleration recursive Newton-Euler columns, dense LDL'
+            (planar_oracle.c:set_invweights);
+      (iii) NumPy, here: kinetic-energy sum over the bodies from the XML numbers (_energy_invweights)."""
+    dof_o, bod_o = O.planar_invweights(body)
+    dof_e, bod_e = _energy_invweights(body)
+    k = _kernel_invweights(ENV_ID[body])
+    nj = len(dof_o) - 3
+    dof_k, bod_k = k[:nj], k[nj:]
+    assert len(bod_k) == len(bod_o)
+    for got in ((dof_k, bod_k), (dof_e[3:], bod_e)):
+        assert np.abs(got[0] / dof_o[3:] - 1).max() <= 1e-12 and np.abs(got[1] / bod_o - 1).max() <= 1e-12
+    assert np.abs(dof_k / dof_e[3:] - 1).max() <= 1e-12 and np.abs(bod_k / bod_e - 1).max() <= 1e-12
+    # no literal table is left in the device headers
+    for hdr in ("cheetah_model.h", "hopper_model.h"):
         txt = open(os.path.join(ROOT, "emei_amd", "csrc", hdr)).read()
-        dof, bod = O.planar_invweights(body)
-        got_dof = [float(x) for x in re.search(r"kDofInvWeight0\[\d+\] = \{([^}]*)\}", txt).group(1).split(",")]
-        got_bod = [float(x) for x in re.search(r"kLinkInvWeight0\[\w+\] = \{([^}]*)\}", txt).group(1).split(",")]
-        assert np.array_equal(got_dof, dof[3:]) and np.array_equal(got_bod, bod[perm])
+        assert not re.search(r"InvWeight0\[\w+\] = \{", txt)
+
+
+def test_pendulum_inverse_weights_against_the_oracle():
+    """InvertedPendulum (slider, hinge) and InvertedDoublePendulum (slider): the kernels' closed forms (pendulum_envs.h:ip_make_model,
+    dpend_model.h:make_model) against the oracle's own 2 x 2 / 3 x 3 inversions."""
+    m = O.ip_model()
+    assert np.allclose(_kernel_invweights(2), [m.invweight_slider, m.invweight_hinge], rtol=1e-13, atol=0)
+    assert np.allclose(_kernel_invweights(7), [O.dpend_invweight()], rtol=1e-13, atol=0)
+
+
+def _impedance(dist, dmin, dmax, width):
+    """solimp (dmin, dmax, width, midpoint .5, power 2), MuJoCo's documented sigmoid"""
+    xx = abs(dist) / width
+    y = 1.0 if xx >= 1 else (2 * xx * xx if xx <= 0.5 else 1 - 2 * (1 - xx) ** 2)
+    return min(max(dmin + y * (dmax - dmin), 1e-4), 0.9999)
+
+
+@pytest.mark.parametrize("body", ["cheetah", "hopper"])
+def test_pyramid_edge_regulariser_is_the_friction_match_of_the_elliptic_cone(body):
+    """The one scaling the oracle used to hold "from memory" (planar_oracle.c:build_rows, R_py = 2 mu^2 R), derived here from what
+    MuJoCo's documentation states and checked on the rows the solver actually sees.
+
+    Documentation, "Computation": every scalar row carries the cost D/2 (J a - aref)^2 where negative, D = 1/R,
+    R = (1 - d)/d * A_ii with d the solimp impedance and A_ii approximated from the qpos0 inverse weights; the elliptic cone's rows are
+    the normal J_n and the tangents J_t with R_t = R_n / impratio; the pyramidal cone replaces them by the 2 (condim - 1) edges
+    J_n +- mu J_t, all with ONE regulariser R_py.
+    Derivation: (a) diagApprox of an edge.  (J_n +- mu J_t) M^-1 (J_n +- mu J_t)' in the isotropic approximation (every translational
+    direction of body b weighs tran_b = body_invweight0[b], cross terms dropped; the floor is static: 0) is tran_b (1 + mu^2): this
+    is R_0 = (1 - d)/d tran_b (1 + mu^2), the contact's leading regulariser.  (b) the pair of edges along one tangent, both active,
+    costs D_py/2 [(x_n + mu x_t)^2 + (x_n - mu x_t)^2] = D_py x_n^2 + mu^2 D_py x_t^2, x = J a - aref: curvature 2 mu^2 D_py along the
+    tangent.  The elliptic cone with impratio = 1 has curvature 1/R_t = 1/R_0 there.  Equal friction curvature: R_py = 2 mu^2 R_0.
+    (The normal curvature then is 2 (condim - 1) D_py, not 1/R_0: the known difference between the two cone models.)"""
+    import test_model_constants as TM
+    from conftest import GOLDEN
+
+    x = np.load(os.path.join(GOLDEN, "model_constants_golden.npz"))
+    t = XML_TAG[body]
+    vec = TM.planar_expected(x, t)
+    nb = len(x[f"{t}_body_names"])
+    ng = (len(vec) - 1 - 6 * nb - 6 * (nb - 1) - 13) // 7
+    geoms = vec[1 + 6 * nb:][: 7 * ng].reshape(ng, 7)
+    margin, _, dmin, dmax, width = vec[-13:-8]
+    _, bod_e = _energy_invweights(body)
+    nv = nb + 2
+    rng = np.random.default_rng(3)
+    seen = 0
+    for _ in range(400):
+        q = rng.normal(0, 0.3, nv)
+        q[1] = rng.uniform(-0.6, -0.3) if body == "cheetah" else 1.25 + rng.uniform(-0.25, -0.05)
+        v = rng.normal(0, 1.0, nv)
+        J, aref, D = O.planar_rows(body, q, v)
+        nlim = int(np.count_nonzero((np.abs(J[:, :3]).sum(axis=1) == 0)))
+        assert (len(J) - nlim) % 4 == 0
+        _, ends = O.planar_geometry(body, q)
+        touching = [(g, e) for g in range(ng) for e in range(2) if ends[g, e, 1] - geoms[g, 5] < margin]
+        assert len(touching) == (len(J) - nlim) // 4
+        for c, (g, e) in enumerate(touching):
+            r0 = nlim + 4 * c
+            mu, b = geoms[g, 6], int(geoms[g, 0])
+            Jn, Jt = 0.5 * (J[r0] + J[r0 + 1]), (J[r0] - J[r0 + 1]) / (2 * mu)
+            assert np.allclose(J[r0 + 2], Jn, atol=1e-14) and np.allclose(J[r0 + 3], Jn, atol=1e-14)
+            assert Jn[1] == 1.0 and Jn[0] == 0.0 and Jt[0] == 1.0 and Jt[1] == 0.0  # a floor contact: n = +z, t = +x
+            imp = _impedance(ends[g, e, 1] - geoms[g, 5] - margin, dmin, dmax, width)
+            R0 = (1 - imp) / imp * bod_e[b] * (1 + mu * mu)  # (a), with the XML-derived inverse weight
+            assert np.allclose(D[r0:r0 + 4], 1.0 / (2 * mu * mu * R0), rtol=1e-11, atol=0)
+            # (b) on the oracle's own rows: an acceleration that moves the point along the tangent only
+            a = np.linalg.lstsq(np.stack([Jn, Jt]), np.array([0.0, 1.0]), rcond=None)[0]
+            pair_cost = 0.5 * sum(D[r] * float(J[r] @ a) ** 2 for r in (r0, r0 + 1))
+            assert np.isclose(pair_cost, 0.5 / R0, rtol=1e-10)
+            seen += 1
+    assert seen >= 200
 
 
 @pytest.mark.parametrize("body", ["cheetah", "hopper"])
