@@ -155,6 +155,14 @@ def self_launch(n_gpus):
     import socket
     import subprocess
 
+    # Under a profiler the preloaded tool library has already initialised the GPU in THIS process, and the ranks would be
+    # its grandchildren: counters attach to the wrong process and a GPU-initialised parent must not spawn a launcher on
+    # this pool.  Profile a rank directly: `torchrun ... ` started first, rocprofv3 in front of each rank's `python bench.py`.
+    preload = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ):
+        sys.stderr.write("bench.py: --gpus N>1 without a launcher refuses to run under a profiler preload "
+                         "(rocprofv3 must wrap each rank's process, not this launcher parent)\n")
+        raise SystemExit(2)
     with socket.socket() as sk:  # a free rendezvous port on the loopback
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

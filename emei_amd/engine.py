@@ -95,7 +95,6 @@ class Engine:
                            *((lambda m, a: (m, L.SOLVERS[solver], a))(*L.pack_env_params(env_params))))
         self._h = C.c_void_p()
         self._host_io = None
-        self._out_ok = {}  # validated `out=` tuples by identity (_check_outputs)
         with torch.cuda.device(self.device):
             L.check(L.lib().emei_create(C.byref(cfg), C.byref(self._h)))
 
@@ -174,26 +173,19 @@ class Engine:
 
     def _check_outputs(self, out, lead):
         """Caller-supplied output buffers go to the ABI as raw pointers (it has no size arguments): a wrong shape, dtype,
-        device or stride would be a silent out-of-bounds device write.  Checked once per distinct `out` tuple object (the
-        per-step path pays one dictionary lookup; tensors are immutable in shape / dtype / device)."""
-        hit = self._out_ok.get(id(out))
-        if hit is not None and hit[0] is out and hit[1] == lead:
-            return out
+        device or stride would be a silent out-of-bounds device write.  Checked on EVERY call and nothing is retained: a
+        tensor can be resize_()d / set_() between calls, and holding callers' buffers alive would pin their device memory."""
         if not isinstance(out, (tuple, list)) or len(out) != 3:
             raise ValueError("out must be (obs, reward, done)")
-        want = ((lead + (self.n_envs, self.obs_dim), torch.float32, "obs"), (lead + (self.n_envs,), torch.float32, "reward"),
-                (lead + (self.n_envs,), torch.uint8, "done"))
-        for t, (shape, dtype, name) in zip(out, want):
+        n = self.n_envs
+        for t, shape, dtype, name in ((out[0], lead + (n, self.obs_dim), torch.float32, "obs"),
+                                      (out[1], lead + (n,), torch.float32, "reward"), (out[2], lead + (n,), torch.uint8, "done")):
             if not isinstance(t, torch.Tensor) or t.device != self.device:
                 raise ValueError(f"out: {name} must be a tensor on {self.device}")
-            if tuple(t.shape) != shape or t.dtype != dtype:
+            if t.shape != shape or t.dtype != dtype:
                 raise ValueError(f"out: {name} is {tuple(t.shape)} {t.dtype}, expected {shape} {dtype}")
             if not t.is_contiguous():
                 raise ValueError(f"out: {name} must be contiguous")
-        if type(out) is tuple:  # a list can have its elements replaced after the check: validated on every call
-            if len(self._out_ok) >= 4096:
-                self._out_ok.clear()
-            self._out_ok[id(out)] = (out, lead)  # holding the tuple keeps its id (and the tensors' shapes) valid
         return out
 
     @_on_device

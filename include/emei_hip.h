@@ -287,7 +287,7 @@ EMEI_API int emei_terminal_ex(int env_id, int64_t n, const float* obs, uint32_t 
  * on the caller's float64 values; reward_out is float64 [n].  EMEI_IO_F32 is the float32 form above. */
 enum emei_io_dtype { EMEI_IO_F32 = 0, EMEI_IO_F64 = 1 };
 /* flags of emei_reward_io */
-#define EMEI_REWARD_BATCH_CTRL_COST 1u /* HalfCheetahRunning only: the control cost is np.sum(np.square(action)) over the
+#define EMEI_REWARD_BATCH_CTRL_COST 1u /* HalfCheetahRunning / HopperRunning only: the control cost is np.sum(np.square(action)) over the
                                           WHOLE batch, as half_cheetah.py:61 executes for B > 1 (no axis argument); the
                                           default (0) sums per env = step() semantics */
 EMEI_API int emei_reward_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* pre_obs, const void* action,

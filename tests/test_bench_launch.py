@@ -24,6 +24,17 @@ def test_self_launch_relays_the_ranks_failure_without_a_gpu():
     assert "needs a GPU" in p.stderr  # both ranks got as far as bench.py's own check: the launcher did start them
 
 
+def test_self_launch_refuses_a_profiler_preload():
+    """`rocprofv3 ... -- python bench.py --gpus 2` would profile the launcher parent (GPU already initialised
+    by the preload) — refused before anything is spawned."""
+    e = dict(os.environ, ROCPROFILER_REGISTER_FORCE_LOAD="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "profiler" in p.stderr and not p.stdout.strip()
+
+
 def test_parent_never_imports_torch_before_launching():
     """the self-launching parent must not initialise the GPU (a later exec / fork from such a process takes the box down):
     its code path ends in self_launch() before the first `import torch`"""

@@ -136,7 +136,8 @@ def test_output_buffers_are_validated():
     a = torch.zeros(128, dtype=torch.uint8, device=eng.device)
     good = eng.alloc_outputs(None)
     eng.step(a, out=good)
-    eng.step(a, out=good)  # the validated tuple is remembered
+    eng.step(a, out=good)
+    assert not hasattr(eng, "_out_ok")  # nothing of the caller's buffers is retained between calls
     assert eng.last_kernel() != 0  # emei_step goes through emei_rollout: the getter covers the step path too
     obs, rew, done = good
     for bad in ((obs[:64], rew, done), (obs, rew.double(), done), (obs, rew, done.to(torch.int32)), (obs.cpu(), rew, done),
@@ -149,12 +150,17 @@ def test_output_buffers_are_validated():
     with pytest.raises(ValueError):
         eng.rollout(acts, out=good)  # step-shaped buffers for a 16-step rollout
     eng.rollout(acts, out=eng.alloc_outputs(16))
-    # a list is validated on every call (its elements can be replaced after the first check)
+    # validated on every call: a list element replaced, or a tensor of an accepted tuple shrunk in place, is seen
     lst = list(eng.alloc_outputs(None))
     eng.step(a, out=lst)
     lst[0] = obs[:64]
     with pytest.raises(ValueError):
         eng.step(a, out=lst)
+    tup = eng.alloc_outputs(None)
+    eng.step(a, out=tup)
+    tup[1].resize_(64)
+    with pytest.raises(ValueError):
+        eng.step(a, out=tup)
 
 
 def test_freeze_reset_unfreeze_keeps_the_auto_reset_episodes():
