@@ -271,6 +271,14 @@ __device__ __forceinline__ double rcp1_r(double d) {
     return __builtin_fma(r0, __builtin_fma(-d, r0, 1.0), r0);
 }
 __device__ __forceinline__ float rcp1_r(float d) { return 1.0f / d; }
+// 1 / sqrt(x): hardware seed + two Newton steps (x = 0 -> +inf, as the seed)
+__device__ __forceinline__ double rsqrt_r(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    r = __builtin_fma(r, __builtin_fma(-hx * r, r, 0.5), r);
+    return __builtin_fma(r, __builtin_fma(-hx * r, r, 0.5), r);
+}
+__device__ __forceinline__ float rsqrt_r(float x) { return 1.0f / sqrtf(x); }
 // v with the sign bit flipped where `mask` (0 or 0x80000000) says so: J * v for J = +-1 in one 32-bit instruction
 __device__ __forceinline__ double flip_sign(double v, uint32_t mask) {
     return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v));

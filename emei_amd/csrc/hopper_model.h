@@ -14,9 +14,12 @@
 //     are Omega_j^2 times the same rotated vectors: 4 sincos per forward-dynamics evaluation.
 //   * the three leg hinges turn about -y (hopper.xml:21,25,29): theta_k = -(phi_child - phi_parent),
 //     so a joint torque tau_k enters as -tau_k on phi_child and +tau_k on phi_parent.
-//   * constraints (3 joint limits, 8 capsule-end/floor contact points with margin and friction): MuJoCo's primal
-//     formulation solved by Newton's method (accel_newton, the default) or round 1's single Gauss-Seidel sweep
-//     (accel), exactly as in cheetah_model.h.
+//   * constraints (3 joint limits, 8 capsule-end/floor contact points with margin and friction, 3 capsule-capsule pairs):
+//     MuJoCo's primal formulation solved by Newton's method (accel_newton, the default) or round 1's single Gauss-Seidel
+//     sweep (accel), exactly as in cheetah_model.h.
+//   * the geoms collide with EACH OTHER (hopper.xml:5: contype = conaffinity = 1 for every geom) wherever their bodies are
+//     not parent and child: torso-leg, torso-foot, thigh-foot.  Both geoms have condim 1, so each pair is ONE frictionless
+//     row along the line between the closest points of the two capsule axes (capsule_pair below).
 // The reference steps this env with RK4 by default (hopper.py:22): body_kernels.h:body_substep.
 #pragma once
 #include <cmath>
@@ -198,6 +201,74 @@ inline int xml_invweights(double* out) {
     for (int k = 0; k < 3; ++k) out[n++] = w.dof[k];
     for (int b = NL - 1; b >= 0; --b) out[n++] = w.link[b];
     return n;
+}
+
+// ---- capsule against capsule.  Pair index: 0 torso-leg, 1 torso-foot, 2 thigh-foot (geom order torso, thigh, leg, foot:
+// the pairs whose bodies are not parent and child, in MuJoCo's (geom1 < geom2) order).
+constexpr int kNumPairs = 3;
+constexpr int kPairGeom[kNumPairs][2] = {{0, 2}, {0, 3}, {1, 3}};
+// a capsule's axis segment in its link frame: centre, unit direction, half length
+struct CapsuleAxis {
+    double cx, cz, ax, az, half;
+};
+constexpr CapsuleAxis capsule_axis(int g) {
+    const Model m = make_model(0.002);
+    const double hx = 0.5 * (m.geom_end[2 * g + 1][0] - m.geom_end[2 * g][0]), hz = 0.5 * (m.geom_end[2 * g + 1][1] - m.geom_end[2 * g][1]);
+    const double len = ce::sqrt(hx * hx + hz * hz);
+    return {0.5 * (m.geom_end[2 * g + 1][0] + m.geom_end[2 * g][0]), 0.5 * (m.geom_end[2 * g + 1][1] + m.geom_end[2 * g][1]), hx / len,
+            hz / len, len};
+}
+// Closest points of the two axis segments the way MuJoCo's capsule-capsule collider finds them (x1, x2 = signed distances
+// from the centres along the unit axes: minimise over the two lines, clamp x1, re-solve x2 and clamp, re-solve x1 if x2
+// was clamped), then sphere against sphere: dist = |c2 - c1| - r1 - r2, normal n from geom 1 to geom 2, contact point p midway
+// between the surfaces.  True while dist < margin.  Coincident closest points (crossing axes) -> n = (1, 0) like MuJoCo's
+// sphere-sphere fallback; (nearly) parallel axes: the determinant is floored, which sends x1 to an end of its segment
+// (MuJoCo emits up to two contacts for exactly parallel capsules: outside the joint ranges for these pairs, not reproduced).
+template <int PAIR, typename R>
+__device__ __forceinline__ bool capsule_pair(const R (&cs)[NL], const R (&sn)[NL], const V2<R> (&org)[NL], R& dist, V2<R>& n, V2<R>& p) {
+    constexpr int G1 = kPairGeom[PAIR][0], G2 = kPairGeom[PAIR][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
+    constexpr CapsuleAxis c1 = capsule_axis(G1), c2 = capsule_axis(G2);
+    constexpr double r1 = kGeom.radius[G1], r2 = kGeom.radius[G2], reach = r1 + r2 + kGeom.margin;
+    const V2<R> o1 = rot(cs[LA], sn[LA], (R)c1.cx, (R)c1.cz), a1 = rot(cs[LA], sn[LA], (R)c1.ax, (R)c1.az);
+    const V2<R> o2 = rot(cs[LB], sn[LB], (R)c2.cx, (R)c2.cz), a2 = rot(cs[LB], sn[LB], (R)c2.ax, (R)c2.az);
+    const V2<R> p1 = {org[LA].x + o1.x, org[LA].z + o1.z}, p2 = {org[LB].x + o2.x, org[LB].z + o2.z};
+    const V2<R> dif = {p1.x - p2.x, p1.z - p2.z};
+    const R mb = -dot(a1, a2), u = -dot(a1, dif), w = dot(a2, dif);
+    R det = fma_r(-mb, mb, R(1));
+    det = det > R(sizeof(R) == 8 ? 1e-15 : 1e-6) ? det : R(sizeof(R) == 8 ? 1e-15 : 1e-6);
+    const R l1 = (R)c1.half, l2 = (R)c2.half;
+    R x1 = fma_r(-mb, w, u) * rcp_r(det);
+    x1 = x1 > l1 ? l1 : (x1 < -l1 ? -l1 : x1);
+    R x2 = fma_r(-mb, x1, w);
+    if (x2 > l2 || x2 < -l2) {
+        x2 = x2 > l2 ? l2 : -l2;
+        x1 = fma_r(-mb, x2, u);
+        x1 = x1 > l1 ? l1 : (x1 < -l1 ? -l1 : x1);
+    }
+    const V2<R> q1 = {fma_r(x1, a1.x, p1.x), fma_r(x1, a1.z, p1.z)};
+    const V2<R> d = {fma_r(x2, a2.x, p2.x) - q1.x, fma_r(x2, a2.z, p2.z) - q1.z};
+    const R len2 = dot(d, d);
+    if (!(len2 < (R)(reach * reach))) return false;
+    const bool degenerate = len2 < R(sizeof(R) == 8 ? 1e-20 : 1e-9);  // |c2 - c1| < 1e-10: oracle PAIR_MINLEN (float32: 3e-5, its noise floor)
+    const R rl = rsqrt_r(degenerate ? R(1) : len2), len = len2 * rl;
+    n = degenerate ? V2<R>{R(1), R(0)} : V2<R>{d.x * rl, d.z * rl};
+    dist = len - (R)(r1 + r2);
+    const R t = fma_r(R(0.5), dist, (R)r1);
+    p = V2<R>{fma_r(t, n.x, q1.x), fma_r(t, n.z, q1.z)};
+    return true;
+}
+// The pair's row on the absolute-angle coordinates: J . u = n . (velocity of p as part of link LB - as part of link LA).  The
+// root translation and every link above LA cancel: entries LB .. LA only (LB < LA), J_i = n x (lever of link i) with levers
+// p - org_LB, the link vectors D_a in between, org_(LA-1) - p.
+template <int PAIR, typename R>
+__device__ __forceinline__ void pair_row(const V2<R> (&org)[NL], const V2<R> (&D)[NL], V2<R> n, V2<R> p, R (&J)[NV]) {
+    constexpr int LA = L_TORSO - kPairGeom[PAIR][0], LB = L_TORSO - kPairGeom[PAIR][1];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) J[i] = R(0);
+    J[LB] = dotperp(n, V2<R>{p.x - org[LB].x, p.z - org[LB].z});
+#pragma unroll
+    for (int a = LB + 1; a < LA; ++a) J[a] = dotperp(n, D[a]);
+    J[LA] = dotperp(n, V2<R>{org[LA - 1].x - p.x, org[LA - 1].z - p.z});
 }
 
 // dense LDL^T of the symmetric 6x6 (lower triangle of A); L in the strict lower triangle, 1/D in invd
@@ -386,6 +457,31 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     contact(integral_constant<int, 0>{}), contact(integral_constant<int, 1>{}), contact(integral_constant<int, 2>{});
     contact(integral_constant<int, 3>{}), contact(integral_constant<int, 4>{}), contact(integral_constant<int, 5>{});
     contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
+    // capsule against capsule: one frictionless row per pair, after the floor points (oracle order)
+    auto pair = [&](auto pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::value, LA = L_TORSO - kPairGeom[P][0], LB = L_TORSO - kPairGeom[P][1];
+        R dist;
+        V2<R> n, p;
+        if (capsule_pair<P>(cs, sn, org, dist, n, p)) {
+            R y[NV], yd[NV];
+            pair_row<P>(org, D, n, p, y);
+            R vn = R(0);
+#pragma unroll
+            for (int i = LB; i <= LA; ++i) vn = fma_r(y[i], u[i], vn);
+            ldl_forward<LB>(A, y);
+            R Aii = R(0), acur = R(0);
+#pragma unroll
+            for (int i = LB; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
+            const R pos = dist - (R)kGeom.margin;
+            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+            const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - acur, Aii + div_r(R(1) - imp, imp) * Aii);
+            if (fn > R(0)) {
+#pragma unroll
+                for (int i = LB; i < NV; ++i) z[i] = fma_r(yd[i], fn, z[i]);
+            }
+        }
+    };
+    pair(integral_constant<int, 0>{}), pair(integral_constant<int, 1>{}), pair(integral_constant<int, 2>{});
     R acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = z[i];
@@ -484,7 +580,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     org[L_THIGH] = V2<R>{org[L_TORSO].x + D[L_TORSO].x, org[L_TORSO].z + D[L_TORSO].z};
     org[L_LEG] = V2<R>{org[L_THIGH].x + D[L_THIGH].x, org[L_THIGH].z + D[L_THIGH].z};
     org[L_FOOT] = V2<R>{org[L_LEG].x + D[L_LEG].x, org[L_LEG].z + D[L_LEG].z};
-    // rows that exist (geometry only): bits 0-2 joint limits, 3-10 contact points
+    // rows that exist (geometry only): bits 0-2 joint limits, 3-10 contact points, 11-13 capsule pairs
     uint32_t rows = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) rows |= ((q[3 + k] < (R)kGeom.lo[k]) | (q[3 + k] > (R)kGeom.hi[k])) ? (1u << k) : 0u;
@@ -493,6 +589,13 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         const int gi = pt / 2, L = L_TORSO - gi;
         const R ez = fma_r((R)kGeom.geom_end[pt][1], cs[L], -((R)kGeom.geom_end[pt][0] * sn[L]));
         rows |= (org[L].z + ez - (R)kGeom.radius[gi] < (R)kGeom.margin) ? (1u << (3 + pt)) : 0u;
+    }
+    {  // bits 11-13: capsule pairs
+        R dist;
+        V2<R> n, p;
+        rows |= capsule_pair<0>(cs, sn, org, dist, n, p) ? (1u << 11) : 0u;
+        rows |= capsule_pair<1>(cs, sn, org, dist, n, p) ? (1u << 12) : 0u;
+        rows |= capsule_pair<2>(cs, sn, org, dist, n, p) ? (1u << 13) : 0u;
     }
     R A[NV][NV], invd[NV], a[NV];
     EMEI_STAT_LANE(0);
@@ -545,7 +648,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             sym_matvec(A, a, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gr[i] -= f[i];
-            uint32_t flags = 0;  // the active set this pass assembles: bit k = limit row k, bits 3 + 3 pt .. = the point's edges (s1, s2, sy)
+            uint32_t flags = 0;  // the active set this pass assembles: bit k = limit row k, bits 3 + 3 pt .. = the point's edges (s1, s2, sy), bit 27 + pair
             auto limit = [&](auto kc) __attribute__((always_inline)) {  // theta_k = phi_P - phi_C: J = +-(e_P - e_C)
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
@@ -622,6 +725,36 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact(integral_constant<int, 0>{}), contact(integral_constant<int, 1>{}), contact(integral_constant<int, 2>{});
             contact(integral_constant<int, 3>{}), contact(integral_constant<int, 4>{}), contact(integral_constant<int, 5>{});
             contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
+            auto pair = [&](auto pc) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value, G1 = kPairGeom[P][0], G2 = kPairGeom[P][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
+                if (rows & (1u << (11 + P))) {
+                    EMEI_STAT_WAVE(4);
+                    R dist, J[NV];
+                    V2<R> n, p;
+                    capsule_pair<P>(cs, sn, org, dist, n, p);
+                    pair_row<P>(org, D, n, p, J);
+                    R vn = R(0), an = R(0);
+#pragma unroll
+                    for (int i = LB; i <= LA; ++i) vn = fma_r(J[i], u[i], vn), an = fma_r(J[i], a[i], an);
+                    const R pos = dist - (R)kGeom.margin;
+                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R x = an + (R)m.cB * vn + (R)m.cK * imp * pos;
+                    if (x < R(0)) {
+                        flags |= 1u << (27 + P);
+                        // frictionless row: diagApprox = the translational inverse weights of both bodies
+                        const R Dw = div_r(imp, (R(1) - imp) * (R)(kInvW.link[LA] + kInvW.link[LB]));
+                        const R t = Dw * x;
+#pragma unroll
+                        for (int i = LB; i <= LA; ++i) {
+                            gr[i] = fma_r(J[i], t, gr[i]);
+                            const R ui = Dw * J[i];
+#pragma unroll
+                            for (int j = LB; j <= i; ++j) A[i][j] = fma_r(ui, J[j], A[i][j]);
+                        }
+                    }
+                }
+            };
+            pair(integral_constant<int, 0>{}), pair(integral_constant<int, 1>{}), pair(integral_constant<int, 2>{});
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
@@ -686,6 +819,22 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact2(integral_constant<int, 0>{}), contact2(integral_constant<int, 1>{}), contact2(integral_constant<int, 2>{});
             contact2(integral_constant<int, 3>{}), contact2(integral_constant<int, 4>{}), contact2(integral_constant<int, 5>{});
             contact2(integral_constant<int, 6>{}), contact2(integral_constant<int, 7>{});
+            auto pair2 = [&](auto pc) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value, LA = L_TORSO - kPairGeom[P][0], LB = L_TORSO - kPairGeom[P][1];
+                if (rows & (1u << (11 + P))) {
+                    R dist, J[NV];
+                    V2<R> n, p;
+                    capsule_pair<P>(cs, sn, org, dist, n, p);
+                    pair_row<P>(org, D, n, p, J);
+                    R vn = R(0), an = R(0);
+#pragma unroll
+                    for (int i = LB; i <= LA; ++i) vn = fma_r(J[i], u[i], vn), an = fma_r(J[i], a[i], an);
+                    const R pos = dist - (R)kGeom.margin;
+                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    again |= (an + (R)m.cB * vn + (R)m.cK * imp * pos < R(0)) ? (1u << (27 + P)) : 0u;
+                }
+            };
+            pair2(integral_constant<int, 0>{}), pair2(integral_constant<int, 1>{}), pair2(integral_constant<int, 2>{});
             if (again == flags) {
                 converged = true;
                 break;

@@ -429,12 +429,23 @@ def xml_constants(model):
 
 def planar_row_mask(body, state):
     """Bit mask of the constraint rows present at each state [n, 2 nv]: limits of the actuated joints in the low bits, then two
-    bits per capsule (its end spheres) in XML geom order."""
+    bits per capsule (its end spheres) in XML geom order, then one bit per colliding capsule pair (hopper: 3)."""
     nv = 9 if body == "cheetah" else 6
     st = np.ascontiguousarray(state, np.float64).reshape(-1, 2 * nv)
     out = np.empty(len(st), np.uint32)
     lib().planar_oracle_row_mask(C.c_int(0 if body == "cheetah" else 1), C.c_int64(len(st)), _p(st, C.c_double), _p(out, C.c_uint32))
     return out
+
+
+def planar_pairs(body, q):
+    """Colliding capsule pairs at configuration q -> rows {g1, g2, touching, dist, normal x, normal z} (hopper: torso-leg,
+    torso-foot, thigh-foot; the cheetah has none: half_cheetah.xml:39 conaffinity 0)."""
+    nv = 9 if body == "cheetah" else 6
+    q = np.ascontiguousarray(q, np.float64).reshape(nv)
+    out = np.zeros((28, 7))
+    lib().planar_oracle_pairs.restype = C.c_int
+    n = lib().planar_oracle_pairs(C.c_int(0 if body == "cheetah" else 1), _p(q, C.c_double), _p(out, C.c_double))
+    return out[:n, :6].copy()
 
 
 def planar_invweights(body):

@@ -71,6 +71,9 @@ typedef struct {
     v2 geom_end[NG][2];
     double geom_radius[NG], geom_friction[NG];
     double contact_margin;
+    /* geom-geom contacts (hopper.xml:5: every geom contype = conaffinity = 1, condim 1): capsule pairs of bodies that are
+     * neither the same nor parent and child (MuJoCo's default parent-child filter) collide, frictionless (condim = max(1, 1)) */
+    int self_collide;
     double stiffness[NV], damping[NV], armature[NV], range_lo[NV], range_hi[NV];
     int limited[NV];
     int act_dof[NU];
@@ -173,8 +176,10 @@ EXPORT int cheetah_oracle_model_size(void) { return (int)sizeof(planar_model_t);
  * (0,1.05)-(0,.6) :22; leg r .04 (0,.6)-(0,.1) :26; foot r .06 (-.13,.1)-(.26,.1) :30.  Default
  * density 1000, no settotalmass.  Joints: armature 1, damping 1, limited (:5), root joints 0/0/free
  * (:15-17); ranges -150..0, -150..0, -45..45 deg; motors gear 200, ctrlrange +-1 (:37-39).
- * Contacts: geom solref (.02 1), solimp (.8 .8 .01), margin .001 (:6); pair friction = max(floor 1
- * (MuJoCo default, :13 sets none), geom): .9 -> 1 for torso/thigh/leg, 2 for the foot. */
+ * Contacts: geom solref (.02 1), solimp (.8 .8 .01), margin .001 (:5); pair friction = max(floor 1
+ * (MuJoCo default, :14 sets none), geom): .9 -> 1 for torso/thigh/leg, 2 for the foot.  The geoms also collide with
+ * EACH OTHER (contype = conaffinity = 1, :5) where their bodies are not parent and child: torso-leg, torso-foot,
+ * thigh-foot, each one frictionless row (geom condim 1): capsule_pair / build_rows below. */
 EXPORT void hopper_oracle_model(planar_model_t* m) {
     memset(m, 0, sizeof(*m));
     m->nb = 4, m->nv = 6, m->ng = 4, m->nu = 3;
@@ -200,6 +205,7 @@ EXPORT void hopper_oracle_model(planar_model_t* m) {
     }
     m->geom_friction[0] = m->geom_friction[1] = m->geom_friction[2] = 1.0, m->geom_friction[3] = 2.0;
     m->contact_margin = 0.001;
+    m->self_collide = 1; /* :5; the cheetah's geoms have conaffinity 0 (half_cheetah.xml:39): floor only */
     m->gravity = 9.81;
     m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.8, m->c_dmax = 0.8, m->c_width = 0.01;
     m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.9, m->l_dmax = 0.95, m->l_width = 0.001; /* MuJoCo joint defaults */
@@ -380,8 +386,74 @@ static void set_invweights(planar_model_t* m) {
 
 /* one scalar constraint row of the primal problem: cost D/2 (J.a - aref)^2 where negative */
 typedef struct { double J[NV], aref, D; } crow_t;
-#define MAXROWS (NV + 4 * 2 * NG)
+#define MAXPAIRS (NG * (NG - 1) / 2)
+#define MAXROWS (NV + 4 * 2 * NG + MAXPAIRS)
 #define MJ_MINVAL 1e-15
+/* closest points nearer than this have no usable direction.  MuJoCo's own threshold is mjMINVAL, but between 1e-15 and 1e-10 the
+ * difference of two O(1) positions is rounding noise, and two implementations would not agree on it: both sides use 1e-10 */
+#define PAIR_MINLEN 1e-10
+
+/* Do capsules g1 < g2 collide at all?  MuJoCo's filters: contype / conaffinity (the model's self_collide), not the same body,
+ * not parent and child. */
+static int pair_collides(const planar_model_t* m, int g1, int g2) {
+    const int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
+    return m->self_collide && b1 != b2 && m->parent[b1] != b2 && m->parent[b2] != b1;
+}
+
+/* Capsule against capsule, both axes in the x-z plane.  MuJoCo's capsule-capsule collider: the closest points of the two axis
+ * SEGMENTS, then sphere against sphere there — dist = |c2 - c1| - r1 - r2, normal from geom 1 to geom 2, contact position midway
+ * between the surfaces; a contact exists while dist < margin.  The closest points are found the way MuJoCo's source and Ericson
+ * (Real-Time Collision Detection, 5.1.9) do it: minimise over the two infinite lines (x1, x2 = signed distances from the
+ * capsule centres along the unit axes), clamp x1 to its segment, re-solve x2 for it and clamp, re-solve x1 if x2 was clamped.
+ * Coincident closest points (the axes cross: a penetration deeper than r1 + r2, which no trajectory reaches through the soft
+ * contact) leave no direction: normal (1, 0), as MuJoCo's sphere-sphere falls back to the x axis (PAIR_MINLEN above).  Exactly parallel axes: MuJoCo emits up to TWO contacts (at the overlapping ends);
+ * this restatement keeps the closer end pair only — a measure-zero configuration, and outside the joint ranges for the three
+ * Hopper pairs (a parallel pair within r1 + r2 would need a hinge folded by 180 degrees).
+ * Returns 1 and (*n, *pos, *dist) if dist < margin. */
+static int capsule_pair(const planar_model_t* m, const kin_t* k, int g1, int g2, v2* n, v2* pos, double* dist_out) {
+    const int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
+    v2 e10 = add(k->org[b1], rot(k->phi[b1], m->geom_end[g1][0])), e11 = add(k->org[b1], rot(k->phi[b1], m->geom_end[g1][1]));
+    v2 e20 = add(k->org[b2], rot(k->phi[b2], m->geom_end[g2][0])), e21 = add(k->org[b2], rot(k->phi[b2], m->geom_end[g2][1]));
+    v2 p1 = scl(0.5, add(e10, e11)), p2 = scl(0.5, add(e20, e21));
+    v2 h1 = scl(0.5, sub(e11, e10)), h2 = scl(0.5, sub(e21, e20));
+    const double l1 = sqrt(dot(h1, h1)), l2 = sqrt(dot(h2, h2)); /* half lengths */
+    v2 a1 = scl(1 / l1, h1), a2 = scl(1 / l2, h2);
+    v2 dif = sub(p1, p2);
+    const double mb = -dot(a1, a2), u = -dot(a1, dif), w = dot(a2, dif), det = 1 - mb * mb;
+    double x1, x2;
+    if (fabs(det) >= MJ_MINVAL) {
+        x1 = (u - mb * w) / det, x2 = (w - mb * u) / det;
+        if (x1 > l1) x1 = l1, x2 = w - mb * x1;
+        else if (x1 < -l1) x1 = -l1, x2 = w - mb * x1;
+        if (x2 > l2) { x2 = l2, x1 = u - mb * x2; x1 = x1 > l1 ? l1 : (x1 < -l1 ? -l1 : x1); }
+        else if (x2 < -l2) { x2 = -l2, x1 = u - mb * x2; x1 = x1 > l1 ? l1 : (x1 < -l1 ? -l1 : x1); }
+    } else { /* parallel: the closest of the four end-to-segment pairs */
+        double best = INFINITY;
+        x1 = x2 = 0;
+        for (int c = 0; c < 4; ++c) {
+            double t1, t2;
+            if (c < 2) { t1 = c ? l1 : -l1; t2 = w - mb * t1; t2 = t2 > l2 ? l2 : (t2 < -l2 ? -l2 : t2); }
+            else { t2 = c == 3 ? l2 : -l2; t1 = u - mb * t2; t1 = t1 > l1 ? l1 : (t1 < -l1 ? -l1 : t1); }
+            v2 d = sub(add(p2, scl(t2, a2)), add(p1, scl(t1, a1)));
+            if (dot(d, d) < best) best = dot(d, d), x1 = t1, x2 = t2;
+        }
+    }
+    v2 c1 = add(p1, scl(x1, a1)), c2 = add(p2, scl(x2, a2)), d = sub(c2, c1);
+    const double len = sqrt(dot(d, d)), r1 = m->geom_radius[g1], r2 = m->geom_radius[g2];
+    const double dist = len - r1 - r2;
+    if (!(dist < m->contact_margin)) return 0;
+    *n = len < PAIR_MINLEN ? V(1, 0) : scl(1 / len, d);
+    *pos = add(c1, scl(r1 + 0.5 * dist, *n));
+    *dist_out = dist;
+    return 1;
+}
+/* The frictionless row of a capsule pair: J = n . (velocity of the contact point as part of body 2 - as part of body 1) */
+static void pair_jacobian(const planar_model_t* m, const kin_t* k, int g1, int g2, v2 n, v2 pos, double J[NV]) {
+    double J1x[NV], J1z[NV], J2x[NV], J2z[NV];
+    point_jacobian(m, k, m->geom_body[g1], pos, J1x, J1z);
+    point_jacobian(m, k, m->geom_body[g2], pos, J2x, J2z);
+    for (int c = 0; c < NV; ++c) J[c] = n.x * (J2x[c] - J1x[c]) + n.z * (J2z[c] - J1z[c]);
+}
 
 static int build_rows(const planar_model_t* m, const kin_t* k, double dt, const double* q, const double* v, crow_t* rows) {
     const int nv = m->nv;
@@ -433,6 +505,23 @@ static int build_rows(const planar_model_t* m, const kin_t* k, double dt, const 
             }
         }
     }
+    for (int g1 = 0; g1 < m->ng; ++g1) /* capsule against capsule (mjCNSTR_CONTACT_FRICTIONLESS: both geoms condim 1) */
+        for (int g2 = g1 + 1; g2 < m->ng; ++g2) {
+            v2 n, p;
+            double dist;
+            if (!pair_collides(m, g1, g2) || !capsule_pair(m, k, g1, g2, &n, &p, &dist)) continue;
+            crow_t* r = &rows[nr++];
+            memset(r, 0, sizeof(*r));
+            pair_jacobian(m, k, g1, g2, n, p, r->J);
+            double Jv = 0;
+            for (int c = 0; c < nv; ++c) Jv += r->J[c] * v[c];
+            double pos = dist - m->contact_margin; /* margin = max of the two geoms' (equal here) */
+            double imp = impedance(pos, m->c_dmin, m->c_dmax, m->c_width);
+            /* diagApprox of a contact's normal row: the translational inverse weights of BOTH bodies (the floor's is 0) */
+            double R = (1 - imp) / imp * (m->body_invweight0[m->geom_body[g1]] + m->body_invweight0[m->geom_body[g2]]);
+            r->aref = -cB * Jv - cK * imp * pos;
+            r->D = 1.0 / (R > MJ_MINVAL ? R : MJ_MINVAL);
+        }
     return nr;
 }
 
@@ -644,6 +733,20 @@ static void planar_accel_sweep1(const void* ctx, double dt, double hd, const dou
             for (int r = 0; r < nv; ++r) acc[r] += wz[r] * fn + wx[r] * ft;
         }
     }
+    for (int g1 = 0; g1 < m->ng; ++g1) /* capsule against capsule: one frictionless row each, after the floor points */
+        for (int g2 = g1 + 1; g2 < m->ng; ++g2) {
+            v2 n, p;
+            double dist, J[NV], w[NV], A = 0, an = 0, vn = 0;
+            if (!pair_collides(m, g1, g2) || !capsule_pair(m, &k, g1, g2, &n, &p, &dist)) continue;
+            pair_jacobian(m, &k, g1, g2, n, p, J);
+            memcpy(w, J, sizeof(w));
+            ldl_solve(nv, M, w);
+            for (int r = 0; r < nv; ++r) A += J[r] * w[r], an += J[r] * acc[r], vn += J[r] * v[r];
+            double pos = dist - m->contact_margin;
+            double imp = impedance(pos, m->c_dmin, m->c_dmax, m->c_width);
+            double fn = (-cB * vn - cK * imp * pos - an) / (A + (1 - imp) / imp * A);
+            if (fn > 0) for (int r = 0; r < nv; ++r) acc[r] += w[r] * fn;
+        }
 }
 
 /* Constructor parameters of the reward / terminal functions in the order of emei_hip.h's enum emei_env_param:
@@ -849,7 +952,8 @@ EXPORT void planar_oracle_count_rows(int body, int64_t n, double dt, const doubl
     }
 }
 /* diagnostics: which rows exist at each state, as a bit mask — bit (i - 3) for a violated limit of joint dof i, bit
- * (nv - 3 + 2 g + e) for end sphere e of capsule g inside the contact margin (the kernels' `rows` word has the same meaning) */
+ * (nv - 3 + 2 g + e) for end sphere e of capsule g inside the contact margin, then one bit per colliding capsule pair (the kernels'
+ * `rows` word has the same meaning) */
 EXPORT void planar_oracle_row_mask(int body, int64_t n, const double* state, uint32_t* mask_out) {
     planar_model_t m;
     if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
@@ -867,12 +971,21 @@ EXPORT void planar_oracle_row_mask(int body, int64_t n, const double* state, uin
                 v2 sp = add(k.org[m.geom_body[g]], rot(k.phi[m.geom_body[g]], m.geom_end[g][e]));
                 if (sp.z - m.geom_radius[g] < m.contact_margin) mask |= 1u << (nv - 3 + 2 * g + e);
             }
+        int pi = 0; /* colliding capsule pairs in (g1, g2) order: hopper torso-leg, torso-foot, thigh-foot */
+        for (int g1 = 0; g1 < m.ng; ++g1)
+            for (int g2 = g1 + 1; g2 < m.ng; ++g2) {
+                v2 n, p;
+                double dist;
+                if (!pair_collides(&m, g1, g2)) continue;
+                if (capsule_pair(&m, &k, g1, g2, &n, &p, &dist)) mask |= 1u << (nv - 3 + 2 * m.ng + pi);
+                ++pi;
+            }
         mask_out[i] = mask;
     }
 }
 /* diagnostics for the tests: the scalar constraint rows the Newton solver sees at one state — Jacobians [nr][nv], reference
  * accelerations, weights D = 1 / R — in build_rows' order (violated limits, then 4 pyramid edges per touching end sphere:
- * n + mu t, n - mu t, n, n).  Returns the row count; at most `cap` rows are written. */
+ * n + mu t, n - mu t, n, n; then one row per touching capsule pair).  Returns the row count; at most `cap` rows are written. */
 EXPORT int planar_oracle_rows(int body, double dt, const double* q, const double* v, int cap, double* J_out, double* aref_out, double* D_out) {
     planar_model_t m;
     if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
@@ -885,6 +998,29 @@ EXPORT int planar_oracle_rows(int body, double dt, const double* q, const double
         aref_out[r] = rows[r].aref, D_out[r] = rows[r].D;
     }
     return nr;
+}
+/* diagnostics for the tests: every colliding capsule pair at q in (g1, g2) order -> out[pair][7] = {g1, g2, touching (dist <
+ * margin), dist, normal x, normal z, 0}; dist / normal are reported for NON-touching pairs too (margin lifted for the query).
+ * Returns the number of pairs. */
+EXPORT int planar_oracle_pairs(int body, const double* q, double* out) {
+    planar_model_t m;
+    if (body == 0) cheetah_oracle_model(&m); else hopper_oracle_model(&m);
+    kin_t k;
+    kinematics(&m, q, &k);
+    const double margin = m.contact_margin;
+    int np = 0;
+    for (int g1 = 0; g1 < m.ng; ++g1)
+        for (int g2 = g1 + 1; g2 < m.ng; ++g2) {
+            v2 n = V(0, 0), p = V(0, 0);
+            double dist = 0;
+            if (!pair_collides(&m, g1, g2)) continue;
+            m.contact_margin = INFINITY;
+            capsule_pair(&m, &k, g1, g2, &n, &p, &dist);
+            m.contact_margin = margin;
+            double* o = out + 7 * np++;
+            o[0] = g1, o[1] = g2, o[2] = dist < margin, o[3] = dist, o[4] = n.x, o[5] = n.z, o[6] = 0;
+        }
+    return np;
 }
 EXPORT void planar_oracle_invweights(int body, double* dof_out, double* body_out) {
     planar_model_t m;

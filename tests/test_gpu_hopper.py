@@ -51,6 +51,32 @@ def test_onestep_vs_oracle(integrator, fr, dt, solver):
     assert not done.any() and not o_term.any()  # hopper.py:104-106: never terminal
 
 
+@pytest.mark.parametrize("integrator,solver", [("rk4", "newton"), ("euler", "newton"), ("rk4", "sweep1"), ("euler", "sweep1")])
+def test_capsule_pairs_vs_oracle(integrator, solver):
+    """hopper.xml:5: the geoms collide with each other (torso-leg, torso-foot, thigh-foot).  Folded legs in the air and on the
+    ground: the oracle sees pair rows in most of these states, several states have all three kinds of row at once, and the
+    kernels' next state agrees to 1e-9."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(21)
+    n = 1536
+    q = np.concatenate([rng.normal(0, 0.3, (n, 1)), rng.uniform(0.1, 2.5, (n, 1)), rng.normal(0, 1.2, (n, 1)),
+                        rng.uniform(-2.9, -0.9, (n, 1)), rng.uniform(-2.9, -1.4, (n, 1)), rng.uniform(-0.9, 0.9, (n, 1))], axis=1)
+    s0 = np.concatenate([q, rng.normal(0, 2.0, (n, 6))], axis=1)
+    mask = O.planar_row_mask("hopper", s0)
+    pairs = (mask >> 11) & 7
+    assert (pairs != 0).mean() > 0.4 and all(((pairs >> b) & 1).sum() >= 5 for b in range(3)), [(pairs >> b & 1).sum() for b in range(3)]
+    assert ((pairs != 0) & ((mask & 7) != 0) & (((mask >> 3) & 0xFF) != 0)).sum() >= 20  # pair + limit + floor rows together
+    act = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32)
+    eng = _engine("HopperRunning", n, freq_rate=4, real_time_scale=0.002, integrator=integrator, solver=solver)
+    eng.set_state(s0)
+    eng.step(torch.as_tensor(act, device=eng.device))
+    o_st, _, _ = O.hopper_step(s0, act.astype(np.float64), 4, 0.002, O.opts(integrator, solver=solver))
+    got = eng.get_state().cpu().numpy()
+    assert rel_err(got, o_st, floor=1.0) <= 1e-9
+    assert eng.solver_cap_hits() == 0
+
+
 def test_f32_mode_tracks_oracle():
     from oracle import oracle as O
 

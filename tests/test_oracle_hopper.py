@@ -189,3 +189,90 @@ def test_custom_constructor_parameters_vs_golden(hopper_golden, mujoco_golden):
         rc = O.cheetah_reward(m["cheetah_obs"], m["cheetah_pre_obs"], m["cheetah_action"], 0.008,
                               dict(forward_reward_weight=2.5, ctrl_cost_weight=0.03))
     assert rel_err(rc, m["cheetah_reward_B1_w2p5_c0p03"], floor=1e-300) <= 1e-12
+
+
+# ---- capsule against capsule (hopper.xml:5: every geom contype = conaffinity = 1, condim 1) -----------------------------
+def _segment_distance_bruteforce(a0, a1, b0, b1, n=2001):
+    """closest distance of two planar segments by dense sampling of both parameters + one local refinement"""
+    s = np.linspace(0, 1, n)
+    pa, pb = a0 + s[:, None] * (a1 - a0), b0 + s[:, None] * (b1 - b0)
+    d2 = ((pa[:, None, :] - pb[None, :, :]) ** 2).sum(-1)
+    i, j = np.unravel_index(np.argmin(d2), d2.shape)
+    si = np.linspace(max(s[i] - 1.0 / n, 0), min(s[i] + 1.0 / n, 1), 401)
+    sj = np.linspace(max(s[j] - 1.0 / n, 0), min(s[j] + 1.0 / n, 1), 401)
+    pa, pb = a0 + si[:, None] * (a1 - a0), b0 + sj[:, None] * (b1 - b0)
+    return np.sqrt(((pa[:, None, :] - pb[None, :, :]) ** 2).sum(-1).min())
+
+
+def test_capsule_pairs_are_the_non_adjacent_bodies_and_their_distance_is_the_segment_distance():
+    """MuJoCo collides geoms of bodies that are not parent and child: torso-leg, torso-foot, thigh-foot (geom ids 0-2, 0-3, 1-3);
+    dist = distance of the axis segments - r1 - r2, checked against a brute-force minimisation over both segments."""
+    rng = np.random.default_rng(11)
+    radius = [0.05, 0.05, 0.04, 0.06]
+    assert len(O.planar_pairs("cheetah", np.zeros(9))) == 0  # half_cheetah.xml:39: conaffinity 0, the floor only
+    for _ in range(60):
+        q = np.concatenate([rng.normal(0, 1, 3), rng.uniform(-3.0, 0.6, 3)])
+        P = O.planar_pairs("hopper", q)
+        assert [tuple(r[:2]) for r in P] == [(0, 2), (0, 3), (1, 3)]
+        _, ends = O.planar_geometry("hopper", q)
+        for g1, g2, touching, dist, nx, nz in P:
+            g1, g2 = int(g1), int(g2)
+            want = _segment_distance_bruteforce(ends[g1, 0], ends[g1, 1], ends[g2, 0], ends[g2, 1]) - radius[g1] - radius[g2]
+            assert abs(dist - want) < 2e-6, (q, g1, g2, dist, want)
+            assert bool(touching) == (dist < 0.001)
+            assert abs(nx * nx + nz * nz - 1) < 1e-12
+    # the init pose: nothing touches (torso-leg are collinear there: the parallel branch), the floor contact rows are unchanged
+    P0 = O.planar_pairs("hopper", [0, 1.25, 0, 0, 0, 0])
+    assert not P0[:, 2].any() and abs(P0[0, 3] - (0.45 - 0.09)) < 1e-14
+
+
+def test_capsule_pair_row_is_the_gradient_of_the_distance():
+    """A frictionless contact row is d(dist)/dq: the Jacobian build_rows assembles from two point Jacobians and the contact
+    normal is compared with central differences of the distance function — a check that is independent of how J is built."""
+    rng = np.random.default_rng(12)
+    found = 0
+    for _ in range(400):
+        q = np.concatenate([rng.normal(0, 0.3, 1), [2.0 + rng.normal(0, 0.1)], rng.normal(0, 1, 1), rng.uniform(-2.9, 0.3, 3)])
+        P = O.planar_pairs("hopper", q)
+        touching = P[:, 2] > 0
+        if not touching.any() or (P[touching, 3] < -0.085).any():  # skip near-crossing axes: the normal is not differentiable there
+            continue
+        J, aref, D = O.planar_rows("hopper", q, np.zeros(6))
+        mask = int(O.planar_row_mask("hopper", np.concatenate([q, np.zeros(6)]))[0])
+        n_lim, n_pts = bin(mask & 0x7).count("1"), bin((mask >> 3) & 0xFF).count("1")
+        assert n_pts == 0  # z = 2: above the floor
+        rows = J[n_lim:]
+        assert len(rows) == touching.sum() and ((mask >> 11) & 7) == sum(1 << i for i in range(3) if touching[i])
+        for r, pi in zip(rows, np.nonzero(touching)[0]):
+            grad = np.zeros(6)
+            for c in range(6):
+                h = 1e-6
+                qp, qm = q.copy(), q.copy()
+                qp[c] += h
+                qm[c] -= h
+                grad[c] = (O.planar_pairs("hopper", qp)[pi, 3] - O.planar_pairs("hopper", qm)[pi, 3]) / (2 * h)
+            assert np.abs(r - grad).max() < 2e-7, (q, pi, r, grad)
+            assert abs(r[0]) < 1e-15 and abs(r[1]) < 1e-15 and abs(r[2]) < 1e-12  # an internal force: no net push on the root
+            found += 1
+        # regulariser: frictionless row, diagApprox = both bodies' translational inverse weights; solimp (.8 .8 .01) -> d = 0.8
+        _, bw = O.planar_invweights("hopper")
+        pairs = [(0, 2), (0, 3), (1, 3)]
+        for d, pi in zip(D[n_lim:], np.nonzero(touching)[0]):
+            assert abs(1 / d - 0.25 * (bw[pairs[pi][0]] + bw[pairs[pi][1]])) < 1e-15
+    assert found >= 30
+
+
+def test_folded_leg_rests_on_the_torso_instead_of_passing_through_it():
+    """hopper.xml:21,25 allow the thigh and the leg to fold by 150 degrees each; with both motors driving the fold at full torque
+    the leg capsule meets the torso capsule.  With the pair row the leg comes to rest ON the torso (1 cm of soft-contact
+    penetration under 200 N m, the knee held at -96 degrees); without it the knee would run on to its own limit at -150."""
+    s = np.zeros((1, 12))
+    s[0, 1] = 3.0  # in the air: the floor plays no part for the first 0.5 s
+    a = np.array([[-1.0, -1.0, 0.0]])
+    seen = False
+    for t in range(60):
+        s, _, _ = O.hopper_step(s, a, 4, 0.002, O.opts("rk4"))
+        seen |= bool(((int(O.planar_row_mask("hopper", s)[0]) >> 11) & 1) != 0)
+    P = O.planar_pairs("hopper", s[0, :6])
+    assert seen and P[0, 2] and -0.02 < P[0, 3] < 0.001, P
+    assert np.degrees(s[0, 3]) < -149 and -105 < np.degrees(s[0, 4]) < -90, np.degrees(s[0, 3:6])
