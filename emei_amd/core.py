@@ -5,8 +5,9 @@ Reference behaviour kept (file:line under /root/reference/emei/core.py):
   * ``OfflineEnv`` (:40-58): ``env_name`` = class name without the "Env" suffix, ``env_params_name`` =
     "&"-joined ``key=value`` pairs in sorted key order (the string test/test_core.py pins).
     The download plumbing (:60-107) is a network fetch and is never performed; datasets are looked up
-    in the reference's directory scheme (``<root>/<env_name>/<env_params_name>/<dataset>``, :82-91) as
-    the ``.npz`` files ``emei_amd.datasets`` writes from GPU rollouts, with the key check of :118-126.
+    in the reference's directory scheme (``<root>/<env_name>-v0/<env_params_name>/<dataset>.h5``, :82-91) as
+    the HDF5 files ``emei_amd.datasets`` writes from GPU rollouts (``emei_amd/h5io.py``: the reference's own
+    container, zoo/util.py:108-111, without h5py) or this package's ``.npz``, with the key check of :118-126.
   * ``EmeiEnv`` (:131-193): causal-graph getters and the abstract batched functions.
 """
 import os
@@ -51,14 +52,27 @@ class OfflineEnv:
 
     @property
     def dataset_dir(self) -> pathlib.Path:
-        """<root>/<env_name>/<env_params_name> (get_path_from_url, core.py:82-91)."""
+        """<root>/<env_name>/<env_params_name>: this package's .npz files (rounds 1-3)."""
         return DATASET_PATH / self.env_name / self.env_params_name
+
+    @property
+    def reference_dataset_dir(self) -> pathlib.Path:
+        """<root>/<env_name>-v0/<env_params_name>: where the reference's get_path_from_url (core.py:82-91) puts the file of
+        URL `.../<env_name>-v0/<params>/<dataset>.h5` (offline_info.py:33-39) — and where it finds one already there."""
+        return DATASET_PATH / f"{self.env_name}-v0" / self.env_params_name
+
+    def _dataset_files(self):
+        """{dataset name: path}; an .h5 in the reference's directory wins over an .npz of the same name"""
+        found = {}
+        for d, pat in ((self.dataset_dir, "*.npz"), (self.reference_dataset_dir, "*.h5")):
+            if d.is_dir():
+                found.update({p.stem: p for p in sorted(d.glob(pat))})
+        return found
 
     @property
     def dataset_names(self):
         """Datasets available for this (env, params): here the local files, never a URL table."""
-        d = self.dataset_dir
-        return sorted(p.stem for p in d.glob("*.npz")) if d.is_dir() else []
+        return sorted(self._dataset_files())
 
     @property
     def env_params_name(self):
@@ -66,14 +80,29 @@ class OfflineEnv:
         return "&".join(f"{k}={params[k]}" for k in sorted(params))
 
     def get_dataset(self, dataset_name):
-        """core.py:109-128 without the download: load `<dataset_dir>/<dataset_name>.npz` and run the same key check."""
-        assert dataset_name in self.dataset_names, (
-            f"dataset {dataset_name!r} not found under {self.dataset_dir}: this build never downloads "
-            "(core.py:95-107); generate one on the GPU with emei_amd.datasets.collect() + save_for_env()")
-        data = dict(np.load(self.dataset_dir / f"{dataset_name}.npz"))
+        """core.py:109-128 without the download: load the local `<dataset_name>.h5` (the reference's container, read by
+        emei_amd/h5io.py as load_h5_data does, :61-81) or `.npz`, then run the same key check."""
+        files = self._dataset_files()
+        assert dataset_name in files, (
+            f"dataset {dataset_name!r} not found under {self.reference_dataset_dir} (.h5) or {self.dataset_dir} (.npz): this "
+            "build never downloads (core.py:95-107); generate one on the GPU with emei_amd.datasets.collect() + save_for_env()")
+        path = files[dataset_name]
+        if path.suffix == ".h5":
+            from . import h5io
+
+            data = h5io.read_h5(path)
+        else:
+            data = dict(np.load(path))
         for key in ["observations", "observations", "actions", "rewards", "dones", "timeouts"]:  # sic, core.py:118-126
             assert key in data, "Dataset is missing key %s" % key
         return data
+
+    @staticmethod
+    def load_h5_data(h5path):
+        """core.py:61-81: {dataset path in the file: array} of every dataset of an HDF5 file"""
+        from . import h5io
+
+        return h5io.read_h5(h5path)
 
 
 class EmeiEnv(Freezable, OfflineEnv):

@@ -95,21 +95,54 @@ def collect(env, n_steps, actions=None, seed=0, device_rng=True, policy=None):
     return data, info
 
 
-def save_npz(dataset, path, rollout_info=None):
-    """The reference writes h5 (zoo/util.py:108-111); h5py is not a dependency here, so the same keys go to .npz."""
-    np.savez_compressed(path, **{k: v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v) for k, v in dataset.items()})
+def _host_arrays(dataset):
+    return {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v) for k, v in dataset.items()}
+
+
+def _write_info(path, rollout_info):
     if rollout_info is not None:
         with open(str(path) + ".info.json", "w") as f:
             json.dump(rollout_info, f, indent=4)
 
 
-def save_for_env(env, dataset, dataset_name, rollout_info=None):
-    """Write `dataset` where `env.get_dataset(dataset_name)` looks for it: the reference's directory scheme
-    <root>/<env_name>/<env_params_name>/<dataset_name> (core.py:82-91), as .npz."""
-    d = env.dataset_dir
+def save_h5(dataset, path, rollout_info=None):
+    """`save_as_h5` of the reference (zoo/util.py:108-111): one HDF5 dataset per key in the root group of a new file, in
+    the on-disk structures h5py itself uses for that call (emei_amd/h5io.py; no h5py needed), so that the reference's
+    `load_h5_data` (emei/core.py:61-81) — or any h5py / libhdf5 reader — opens it."""
+    from . import h5io
+
+    h5io.write_h5(path, _host_arrays(dataset))
+    _write_info(path, rollout_info)
+
+
+def load_h5(path):
+    """`OfflineEnv.load_h5_data` (emei/core.py:61-81) + the key check of :118-126."""
+    from . import h5io
+
+    d = h5io.read_h5(path)
+    for key in DATASET_KEYS:
+        assert key in d, "Dataset is missing key %s" % key
+    return d
+
+
+def save_npz(dataset, path, rollout_info=None):
+    """The same keys as a compressed .npz (this package's own container; the reference reads .h5: save_h5)."""
+    np.savez_compressed(path, **_host_arrays(dataset))
+    _write_info(path, rollout_info)
+
+
+def save_for_env(env, dataset, dataset_name, rollout_info=None, fmt="h5"):
+    """Write `dataset` where `env.get_dataset(dataset_name)` looks for it.
+    fmt "h5" (default): `<root>/<env_name>-v0/<env_params_name>/<dataset_name>.h5` — exactly the path the REFERENCE's
+    `get_dataset` resolves its URL to (core.py:82-91 with the URL scheme of offline_info.py:33-39) and loads from when the
+    file already exists (core.py:95-103 downloads only a missing file), in the reference's container (zoo/util.py:108-111).
+    fmt "npz": `<root>/<env_name>/<env_params_name>/<dataset_name>.npz`, rounds 1-3's layout."""
+    if fmt not in ("h5", "npz"):
+        raise ValueError(f"fmt {fmt!r}: 'h5' or 'npz'")
+    d = env.reference_dataset_dir if fmt == "h5" else env.dataset_dir
     d.mkdir(parents=True, exist_ok=True)
-    path = d / f"{dataset_name}.npz"
-    save_npz(dataset, path, rollout_info)
+    path = d / f"{dataset_name}.{fmt}"
+    (save_h5 if fmt == "h5" else save_npz)(dataset, path, rollout_info)
     return path
 
 

@@ -48,6 +48,11 @@ def test_cartpole_dataset_rows_are_transitions(tmp_path):
     datasets.save_npz(data, p, info)
     back = datasets.load_npz(p)
     assert np.array_equal(back["observations"], d["observations"]) and (tmp_path / "CartPoleBalancing-random.npz.info.json").exists()
+    # ... and through the reference's own container (zoo/util.py:108-111 save_as_h5 / core.py:61-81 load_h5_data), bit for bit
+    h5 = tmp_path / "CartPoleBalancing-random.h5"
+    datasets.save_h5(data, h5, info)
+    back = datasets.load_h5(h5)
+    assert set(back) == set(datasets.DATASET_KEYS) and all(np.array_equal(back[k], d[k]) and back[k].dtype == d[k].dtype for k in d)
 
 
 def test_timeouts_and_continuous_actions():

@@ -188,12 +188,15 @@ def test_product_fails_loudly_without_gpu():
 
 
 def test_offline_dataset_lookup_is_local_only(tmp_path, monkeypatch):
-    """core.py:82-128: datasets live under <root>/<env_name>/<env_params_name>/; this build never downloads."""
-    from emei_amd import core, datasets
+    """core.py:82-128: datasets live under <root>/<env_name>-v0/<env_params_name>/<name>.h5 (the path the reference's URL scheme
+    resolves to, in the reference's HDF5 container) or, rounds 1-3, <root>/<env_name>/<params>/<name>.npz; never downloaded."""
+    from emei_amd import core, datasets, h5io
 
     monkeypatch.setattr(core, "DATASET_PATH", tmp_path)
     env = emei_amd.CartPoleSwingUpEnv(freq_rate=2)
-    assert env.dataset_dir == tmp_path / "CartPoleSwingUp" / "freq_rate=2&integrator=euler&real_time_scale=0.02"
+    params = "freq_rate=2&integrator=euler&real_time_scale=0.02"
+    assert env.dataset_dir == tmp_path / "CartPoleSwingUp" / params
+    assert env.reference_dataset_dir == tmp_path / "CartPoleSwingUp-v0" / params
     assert env.dataset_names == []
     with pytest.raises(AssertionError):  # `assert dataset_name in self._offline_dataset_urls`, core.py:110
         env.get_dataset("uniform")
@@ -202,14 +205,21 @@ def test_offline_dataset_lookup_is_local_only(tmp_path, monkeypatch):
             "actions": np.zeros((n, 1), np.float32), "rewards": np.zeros(n, np.float32), "dones": np.zeros(n, np.float32),
             "timeouts": np.zeros(n, np.float32)}
     path = datasets.save_for_env(env, data, "uniform", rollout_info={"total_sample_num": n})
-    assert path.exists() and env.dataset_names == ["uniform"]
+    assert path == env.reference_dataset_dir / "uniform.h5" and path.exists() and env.dataset_names == ["uniform"]
+    assert path.read_bytes()[:8] == h5io.SIGNATURE
     got = env.get_dataset("uniform")
-    assert set(datasets.DATASET_KEYS) <= set(got) and np.array_equal(got["next_observations"], data["next_observations"])
+    assert set(datasets.DATASET_KEYS) == set(got) and np.array_equal(got["next_observations"], data["next_observations"])
+    assert set(env.load_h5_data(path)) == set(datasets.DATASET_KEYS)  # core.py:61-81
+    old = datasets.save_for_env(env, data, "legacy", fmt="npz")
+    assert old == env.dataset_dir / "legacy.npz" and env.dataset_names == ["legacy", "uniform"]
+    assert np.array_equal(env.get_dataset("legacy")["observations"], data["observations"])
     bad = dict(data)
     del bad["timeouts"]
-    datasets.save_for_env(env, bad, "broken")
-    with pytest.raises(AssertionError, match="Dataset is missing key timeouts"):  # core.py:118-126
-        env.get_dataset("broken")
+    for fmt in ("h5", "npz"):
+        datasets.save_for_env(env, bad, "broken", fmt=fmt)
+        with pytest.raises(AssertionError, match="Dataset is missing key timeouts"):  # core.py:118-126
+            env.get_dataset("broken")
+        (env.reference_dataset_dir / "broken.h5").unlink(missing_ok=True)
 
 
 def test_mujoco_backed_envs_warn_that_parity_is_unpinned():
