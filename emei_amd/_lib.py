@@ -31,7 +31,7 @@ ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
 FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
-ABI_VERSION = 4
+ABI_VERSION = 5
 IO_F32, IO_F64 = 0, 1  # enum emei_io_dtype
 REWARD_BATCH_CTRL_COST = 1  # flag of emei_reward_io (half_cheetah.py:61 / hopper.py:98: np.sum over the whole batch)
 # enum emei_kernel_id (emei_last_rollout_kernel)
@@ -98,6 +98,7 @@ SYMBOLS = {
     "emei_freeze": (C.c_int, [_vp, _vp]),
     "emei_unfreeze": (C.c_int, [_vp, _vp]),
     "emei_step": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
+    "emei_step_host": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _u32, _vp]),
     "emei_rollout": (C.c_int, [_vp, _i32, _vp, C.c_int, _vp, _vp, _vp, _u32, _vp]),
     "emei_compact_done": (C.c_int, [_vp, _vp, _vp, _vp]),
     "emei_get_counters": (C.c_int, [_vp, _vp, _vp, _vp]),

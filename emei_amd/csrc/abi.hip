@@ -32,6 +32,8 @@ struct emei_env {
     unsigned long long* cap_hits;  // device counter: Newton solves that ended at the iteration cap (emei_get_solver_cap_hits)
     bool has_state, frozen;
     int last_kernel;  // enum emei_kernel_id of the last emei_step / emei_rollout
+    uint32_t* host_flag = nullptr;  // emei_step_host: page-locked completion word (allocated on first use) ...
+    uint32_t flag_seq = 0;          // ... and the value the next launch stores into it
     PendParams pend;
     const void* trig;
 };
@@ -292,6 +294,7 @@ extern "C" EMEI_API int emei_destroy(emei_env* h) {
     (void)hipFree(h->frozen_steps);
     (void)hipFree(h->frozen_episode);
     (void)hipFree(h->cap_hits);
+    if (h->host_flag) (void)hipHostFree(h->host_flag);
     delete h;
     return EMEI_OK;
 }
@@ -505,6 +508,55 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
         rc = body_launch(L);
     }
     return rc == EMEI_OK ? rc : fail(rc, "emei_rollout: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+}
+
+extern "C" EMEI_API int emei_step_host(emei_env* h, const void* actions_host, int action_dtype, double* obs64_host, float* obs32_host,
+                                       float* reward_host, uint8_t* done_host, uint32_t flags, void* stream) {
+    if (!h || !actions_host || !obs64_host || !obs32_host || !reward_host || !done_host)
+        return fail(EMEI_ERR_INVALID, "emei_step_host: null argument");
+    EMEI_ON_DEVICE(h, "emei_step_host");
+    if (!h->has_state) return fail(EMEI_ERR_STATE, "Call reset before using step method.");  // base_control.py:67
+    if (flags & ~EMEI_FLAG_AUTO_RESET) return fail(EMEI_ERR_INVALID, "emei_step_host: unknown flags 0x%x", flags);
+    if (check_action_dtype(h, action_dtype) != EMEI_OK) return EMEI_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (!steps_as_body(h->cfg) && h->cfg.n_envs == 1) {
+        // ONE launch: the generic rollout kernel also writes the float64 observation and ends with a completion word
+        if (!h->host_flag) {
+            HIP_TRY(hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault));
+            *h->host_flag = 0;
+        }
+        PendLaunch L = pend_base(h, stream);
+        L.op = PEND_OP_ROLLOUT;
+        L.actions = actions_host;
+        L.action_dtype = action_dtype;
+        L.obs_out = obs32_host, L.reward_out = reward_host, L.done_out = done_host, L.obs_f64 = obs64_host;
+        L.n_steps = 1;
+        L.flags = flags;
+        L.selected = &h->last_kernel;
+        L.host_flag = h->host_flag;
+        L.flag_value = ++h->flag_seq;
+        if (L.flag_value == 0) L.flag_value = ++h->flag_seq;  // 0 is the word's initial content
+        int rc = pend_launch(L);
+        if (rc != EMEI_OK) return fail(rc, "emei_step_host: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+        // poll the word (the kernel's last store, system scope); a launch that does not finish within ~5 ms is handed to the
+        // runtime's own wait, which also surfaces a device fault
+        volatile uint32_t* flag = h->host_flag;
+        for (int spin = 0; spin < 4000000; ++spin) {
+            if (*flag == L.flag_value) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                return EMEI_OK;
+            }
+            __builtin_ia32_pause();
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        return *flag == L.flag_value ? EMEI_OK : fail(EMEI_ERR_HIP, "emei_step_host: the kernel finished without its completion word");
+    }
+    int rc = emei_rollout(h, 1, actions_host, action_dtype, obs32_host, reward_host, done_host, flags, stream);
+    if (rc != EMEI_OK) return rc;
+    rc = emei_get_obs(h, obs64_host, stream);
+    if (rc != EMEI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return EMEI_OK;
 }
 
 extern "C" EMEI_API int emei_step(emei_env* h, const void* actions, int action_dtype, float* obs_out, float* reward_out,

@@ -33,6 +33,11 @@ struct PendLaunch {
     PendParams p;
     hipStream_t stream = nullptr;
     int* selected = nullptr;  // out: enum emei_kernel_id of the rollout kernel launched (emei_last_rollout_kernel)
+    // emei_step_host (PEND_OP_ROLLOUT with n_steps = 1): obs_f64 also receives the post-step observation of the STATE in
+    // float64 (what emei_get_obs would return), and for n = 1 the kernel ends by storing flag_value to *host_flag (host
+    // memory, system scope, after everything else it wrote)
+    uint32_t* host_flag = nullptr;
+    uint32_t flag_value = 0;
 };
 
 // pendulum_kernels.hip

@@ -29,6 +29,10 @@ struct RolloutArgs {
     uint32_t flags;
     uint64_t seed, env_offset;
     typename Env::Params p;
+    // the generic kernel only (emei_step_host; appended so that no other field moves): see launch.h
+    double* obs_f64;
+    uint32_t* host_flag;
+    uint32_t flag_value;
 };
 
 // emei_step (n_steps = 1) and emei_rollout (n_steps = T): base_control.py:61-83 /
@@ -121,6 +125,17 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
     // done bits of the last step, one 64-bit word per wave, for emei_compact_done
     unsigned long long m = __ballot(done != 0);
     if ((threadIdx.x & (kWave - 1)) == 0) a.done_mask[i / kWave] = m;
+    if (a.obs_f64) {  // emei_step_host: the state's observation in float64 (after an auto-reset: the new episode's), as emei_get_obs
+        R o[4];
+        Env::obs_of(s, o);
+        double2* dst = (double2*)(a.obs_f64 + 4 * i);
+        dst[0] = make_double2((double)o[0], (double)o[1]);
+        dst[1] = make_double2((double)o[2], (double)o[3]);
+    }
+    if (a.host_flag) {  // n = 1 (checked on the host): this thread wrote every result; release them to the host, then the flag
+        __threadfence_system();
+        __hip_atomic_store(a.host_flag, a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -520,6 +535,9 @@ static int launch_env(const PendLaunch& L) {
     a.seed = L.seed;
     a.env_offset = L.env_offset;
     a.p = Env::make_params(L.p);
+    a.obs_f64 = L.op == PEND_OP_ROLLOUT ? L.obs_f64 : nullptr;
+    a.host_flag = L.op == PEND_OP_ROLLOUT ? L.host_flag : nullptr;
+    a.flag_value = L.flag_value;
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case PEND_OP_ROLLOUT: {

@@ -22,6 +22,13 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _stream_handle(device_index):
+    """the same as an integer for a pre-bound ctypes call (emei_step_host)"""
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -197,30 +204,41 @@ class Engine:
                                   L.FLAG_AUTO_RESET if auto_reset else 0, _stream()))
         return obs, rew, done
 
-    @_on_device
     def step_host(self, action, auto_reset=False):
-        """The gym-style single-env call (`env.step(a)` of base_control.py:61-83 with host values in and out):
-        actions and results live in pinned host memory that the kernels address directly, so a step is
-        two launches (emei_step, emei_get_obs) and one stream synchronisation — no copy calls.
+        """The gym-style single-env call (`env.step(a)` of base_control.py:61-83 with host values in and out) through
+        emei_step_host: actions and results live in pinned host memory that the kernels address directly; for one env of the
+        4-state family a step is ONE launch whose last store is a completion word the library polls (no copy, no stream
+        synchronisation), otherwise step + emei_get_obs + one synchronisation.
         action: array-like [N(,act_dim)] -> (obs float64 [N,obs_dim] of the post-step state, obs float32
         [N,obs_dim] as emitted by the step (pre auto-reset), reward float32 [N], done uint8 [N]) as NumPy
         views of the pinned buffers (valid until the next call)."""
         io = self._host_io
         if io is None:
-            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
-            ashape = (self.n_envs,) if self.act_dim <= 1 else (self.n_envs, self.act_dim)
-            act = pin(ashape, torch.int64 if self.act_dim == 0 else torch.float32)
-            bufs = (act, pin((self.n_envs, self.obs_dim), torch.float64), pin((self.n_envs, self.obs_dim), torch.float32),
-                    pin((self.n_envs,), torch.float32), pin((self.n_envs,), torch.uint8))
-            io = self._host_io = bufs + tuple(b.numpy() for b in bufs)
-        act, obs64, obs32, rew, done, act_np, obs64_np, obs32_np, rew_np, done_np = io
+            io = self._host_io = self._make_host_io()
+        act_np, obs64_np, obs32_np, rew_np, done_np, call, flag_auto = io
         act_np[...] = action
-        lib, st = L.lib(), _stream()
-        L.check(lib.emei_step(self._h, _ptr(act), _ACT_DTYPES[act.dtype], _ptr(obs32), _ptr(rew), _ptr(done),
-                              L.FLAG_AUTO_RESET if auto_reset else 0, st))
-        L.check(lib.emei_get_obs(self._h, _ptr(obs64), st))
-        torch.cuda.current_stream().synchronize()
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                rc = call(flag_auto if auto_reset else 0, _stream_handle(self.device.index))
+        else:
+            rc = call(flag_auto if auto_reset else 0, _stream_handle(self.device.index))
+        if rc:
+            L.check(rc)
         return obs64_np, obs32_np, rew_np, done_np
+
+    def _make_host_io(self):
+        import functools
+
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+        ashape = (self.n_envs,) if self.act_dim <= 1 else (self.n_envs, self.act_dim)
+        act = pin(ashape, torch.int64 if self.act_dim == 0 else torch.float32)
+        bufs = (act, pin((self.n_envs, self.obs_dim), torch.float64), pin((self.n_envs, self.obs_dim), torch.float32),
+                pin((self.n_envs,), torch.float32), pin((self.n_envs,), torch.uint8))
+        self._host_bufs = bufs  # keeps the pinned allocations alive
+        # the pointers never change: bind them once (a ctypes call costs per converted argument)
+        call = functools.partial(L.lib().emei_step_host, self._h, _ptr(act), _ACT_DTYPES[act.dtype], _ptr(bufs[1]), _ptr(bufs[2]),
+                                 _ptr(bufs[3]), _ptr(bufs[4]))
+        return tuple(b.numpy() for b in bufs) + (call, L.FLAG_AUTO_RESET)
 
     @_on_device
     def rollout(self, actions, auto_reset=False, out=None):

@@ -12,6 +12,19 @@ import numpy as np
 
 from ..core import EmeiEnv
 
+_Tensor = None
+
+
+def _is_tensor(x):
+    """isinstance(x, torch.Tensor) without importing torch on every step() (the import is a dictionary lookup, but the
+    single-env path counts microseconds)"""
+    global _Tensor
+    if _Tensor is None:
+        import torch
+
+        _Tensor = torch.Tensor
+    return isinstance(x, _Tensor)
+
 
 class HipEnv(EmeiEnv):
     ENGINE_NAME = None  # key of emei_amd._lib.ENV_IDS
@@ -139,17 +152,18 @@ class HipEnv(EmeiEnv):
         raise NotImplementedError
 
     def step(self, action):
-        import torch
-
         assert self.state is not None, "Call reset before using step method."  # base_control.py:67
-        eng = self.engine
-        if self.num_envs == 1 and not isinstance(action, torch.Tensor):
+        if self.num_envs == 1 and not _is_tensor(action):
+            # the gym single-env call: one emei_step_host (engine.py:step_host); ~11 us for CartPole, of which ~3 are this method
             act = self._check_single_action(action)
-            obs64, obs32, rew, done = eng.step_host(act, auto_reset=self.auto_reset)
+            obs64, obs32, rew, done = (self._engine or self.engine).step_host(act, self.auto_reset)
             d = int(done[0])
             # after an auto-reset the handle already holds the next episode's state: report the step's own obs
-            obs = obs64[0].copy() if not (self.auto_reset and d) else obs32[0].astype(np.float64)
+            obs = obs64[0].copy() if not (d and self.auto_reset) else obs32[0].astype(np.float64)
             return obs, np.float64(rew[0]), np.bool_(d & 1), bool(d & 2), {}
+        import torch
+
+        eng = self.engine
         a = action if isinstance(action, torch.Tensor) else torch.as_tensor(action)
         a = a.to(eng.device)
         if eng.act_dim == 0 and a.dtype not in (torch.uint8, torch.int32, torch.int64):

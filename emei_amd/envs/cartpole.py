@@ -29,10 +29,11 @@ class BaseCartPoleEnv(HipEnv):
         self.observation_space = spaces.Box(-high, high, dtype=np.float32)
 
     def _check_single_action(self, action):
+        if type(action) is int and 0 <= action < 2:  # the common call; everything else takes the reference's own checks
+            return action
         if isinstance(action, int):  # base_control.py:62-63
             action = np.asarray(action)
-        err_msg = f"{action!r} ({type(action)}) invalid"
-        assert self.action_space.contains(action), err_msg  # base_control.py:65-66
+        assert self.action_space.contains(action), f"{action!r} ({type(action)}) invalid"  # base_control.py:65-66
         return np.asarray(action, dtype=np.int64)
 
     def _extract_action(self, action):

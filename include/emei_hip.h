@@ -27,7 +27,7 @@ extern "C" {
  * 3: the *_io stateless entry points (float64 observations), emei_freeze / emei_unfreeze snapshot the reset key,
  *    emei_model_constants, emei_get_solver_cap_hits.
  * 4: emei_model_invweights. */
-#define EMEI_ABI_VERSION 4
+#define EMEI_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -228,6 +228,19 @@ EMEI_API int emei_set_seed(emei_env* h, uint64_t seed);
  * Any output pointer may be NULL to skip that output. */
 EMEI_API int emei_step(emei_env* h, const void* actions, int action_dtype, float* obs_out, float* reward_out,
               uint8_t* done_out, uint32_t flags, void* stream);
+
+/* The gym single-env call itself — `obs, reward, terminal, truncated, info = env.step(action)` of base_control.py:61-83 /
+ * mujoco_env.py:157-167 with HOST values in and out — as one synchronous call: every pointer is page-locked host memory
+ * that the device can address (hipHostMalloc / hipHostRegister / torch pin_memory), the kernels read the action from it
+ * and write the results into it, and the function returns when the results are visible to the host.
+ *   actions_host  as `actions` of emei_step
+ *   obs64_host    [n_envs, obs_dim] float64: the observation of the STATE after the step (the float64 array the reference
+ *                 returns; after an auto-reset the new episode's first observation, as emei_get_obs)
+ *   obs32_host, reward_host, done_host: as emei_step (the step's own observation, before any auto-reset)
+ * One launch and no stream synchronisation for a single env of the 4-state family (the kernel's last store is a completion
+ * word the host polls); step + emei_get_obs + a stream synchronisation otherwise.  None of the pointers may be NULL. */
+EMEI_API int emei_step_host(emei_env* h, const void* actions_host, int action_dtype, double* obs64_host, float* obs32_host,
+                   float* reward_host, uint8_t* done_host, uint32_t flags, void* stream);
 
 /* n_steps fused steps in ONE launch, state kept in registers (the caller loops of zoo/util.py:54-73
  * and emei/util.py:14-36 collapsed): actions [n_steps, n_envs(, act_dim)], obs_out

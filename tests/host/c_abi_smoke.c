@@ -56,6 +56,48 @@ int main(int argc, char** argv) {
         mean_th += o[2] / n;
     }
     if (!(max_x < 5.0) || !(fabs(mean_th - 3.14159) < 0.5)) { printf("implausible: max|x| %.3f mean theta %.3f\n", max_x, mean_th); return 1; }
+    /* the gym single-env call with host values (emei_step_host): 64 steps of one env through page-locked host memory must equal
+     * the same env stepped with emei_step on device buffers, bit for bit, and the float64 observation must be the state's */
+    {
+        cfg.n_envs = 1;
+        emei_env *ha = NULL, *hb = NULL;
+        CHECK_EMEI(emei_create(&cfg, &ha));
+        CHECK_EMEI(emei_create(&cfg, &hb));
+        CHECK_EMEI(emei_reset(ha, 11, NULL));
+        CHECK_EMEI(emei_reset(hb, 11, NULL));
+        unsigned char* pin = NULL;
+        CHECK_HIP(hipHostMalloc((void**)&pin, 256, 0));
+        unsigned char* a_p = pin;            /* action */
+        double* o64_p = (double*)(pin + 64); /* 4 doubles */
+        float* o32_p = (float*)(pin + 128);
+        float* r_p = (float*)(pin + 160);
+        unsigned char* d_p = pin + 192;
+        double state[4];
+        double* state_d = NULL;
+        CHECK_HIP(hipMalloc((void**)&state_d, sizeof(state)));
+        if (emei_step_host(ha, a_p, EMEI_ACT_U8, NULL, o32_p, r_p, d_p, 0, NULL) != EMEI_ERR_INVALID) { printf("null check\n"); return 1; }
+        for (int t = 0; t < 64; ++t) {
+            *a_p = act_h[t];
+            CHECK_EMEI(emei_step_host(ha, a_p, EMEI_ACT_U8, o64_p, o32_p, r_p, d_p, 0, NULL));
+            float o_ref[4], r_ref;
+            unsigned char d_ref;
+            CHECK_HIP(hipMemcpy(act_d, a_p, 1, hipMemcpyHostToDevice));
+            CHECK_EMEI(emei_step(hb, act_d, EMEI_ACT_U8, obs_d, rew_d, done_d, 0, NULL));
+            CHECK_EMEI(emei_get_state(hb, state_d, NULL));
+            CHECK_HIP(hipDeviceSynchronize());
+            CHECK_HIP(hipMemcpy(o_ref, obs_d, sizeof(o_ref), hipMemcpyDeviceToHost));
+            CHECK_HIP(hipMemcpy(&r_ref, rew_d, sizeof(r_ref), hipMemcpyDeviceToHost));
+            CHECK_HIP(hipMemcpy(&d_ref, done_d, 1, hipMemcpyDeviceToHost));
+            CHECK_HIP(hipMemcpy(state, state_d, sizeof(state), hipMemcpyDeviceToHost));
+            if (memcmp(o_ref, o32_p, sizeof(o_ref)) || memcmp(&r_ref, r_p, 4) || d_ref != *d_p || memcmp(state, o64_p, sizeof(state))) {
+                printf("emei_step_host differs from emei_step at step %d\n", t);
+                return 1;
+            }
+        }
+        CHECK_EMEI(emei_destroy(ha));
+        CHECK_EMEI(emei_destroy(hb));
+        CHECK_HIP(hipHostFree(pin));
+    }
     printf("C ABI OK: %lld envs x %d steps, max|x| %.3f, mean theta %.3f\n", (long long)n, T, max_x, mean_th);
     return 0;
 }
