@@ -375,6 +375,40 @@ def main():
                        "note": "whole-pass average: the all-gathers overlap the rollout launches"
                                + ("; with --gather per_chunk / per_step every rank receives the whole observation return of its peers, "
                                   "so N > 1 is bound by xGMI by design, not by the rollout kernel" if gather != "final" else "")}
+    if world > 1:
+        # What the rollout kernels alone sustain, per rank and summed: N envs x the steps of one launch / that launch's duration,
+        # measured on every rank with no collective between the launches (timed_launches_ms).  Beside `value` it separates how
+        # the KERNEL scales with N from what the chosen observation exchange costs.
+        mine = N * T_launch / (kernel_ms * 1e-3)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        out["compute_only"] = {"value": float(sum(per_rank)), "unit": "env-steps/s", "per_rank": [float(v) for v in per_rank],
+                               "what": "sum over ranks of envs_per_gpu x steps per launch / rollout-kernel launch duration (HIP events "
+                                       "around back-to-back launches, no collective in the span)"}
+        if gather != "final":
+            # ... and the same job with only the LAST observation of each pass exchanged (--gather final), timed in this run under
+            # the same barrier / max-over-ranks rule: `value` keeps the default mode's number
+            sf = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
+                                world=world, device=local_rank, seed=0, integrator=a.integrator or w.get("integrator", "euler"),
+                                gather="final", solver=a.solver)
+            sf.make_synthetic_inputs()
+            for _ in range(max(a.warmup, 2)):
+                sf.run_pass()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(a.steps):
+                sf.run_pass()
+            sf.wait_gathers()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tf = torch.tensor([time.perf_counter() - tf], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            out["value_final_gather"] = {"value": total_env_steps / float(tf.item()), "unit": "env-steps/s",
+                                         "ms_per_step": float(tf.item()) / a.steps * 1e3, "gather": "final",
+                                         "what": "the same job, same run, exchanging only the last [n, obs_dim] observation of each pass"}
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

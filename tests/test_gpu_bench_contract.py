@@ -94,6 +94,14 @@ def test_two_rank_line_over_gloo_sharing_the_gpu(how):
     la = j["launch"]
     assert la["ranks"] == 2 and la["backend"] == "gloo" and len(la["devices"]) == 2 and all(d.startswith("cuda:0") for d in la["devices"])
     assert la["self_launched"] == (how == "direct")
+    # beside `value` (the default per_chunk exchange) the kernels' own rate per rank and the final-gather job
+    co = j["compute_only"]
+    assert len(co["per_rank"]) == 2 and co["value"] == pytest.approx(sum(co["per_rank"])) and co["unit"] == "env-steps/s"
+    assert co["per_rank"][0] == pytest.approx(131072 * 125 / (j["roofline"]["kernel_ms"] * 1e-3), rel=1e-6)  # rank 0's own launches
+    assert co["value"] >= j["value"]  # the exchange can only cost
+    vf = j["value_final_gather"]
+    assert vf["gather"] == "final" and vf["value"] == pytest.approx(2 * 131072 * 1000 / (vf["ms_per_step"] * 1e-3), rel=1e-6)
+    assert vf["value"] >= 0.9 * j["value"]
 
 
 def test_a_failing_rank_fails_the_self_launched_bench():
