@@ -13,11 +13,10 @@ import sys
 import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from gen_h5_golden import expected  # noqa: E402
+from emei_amd import h5io
+from oracle.gen_h5_golden import expected  # the arrays the fixture was written from (functions of their shapes)
 
-from emei_amd import h5io  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CONDA_PY = "/opt/conda/bin/python3.9"
 H5DUMP = "/opt/conda/bin/h5dump"
