@@ -56,6 +56,18 @@ using cheetah::impedance;
 using cheetah::rot;
 using cheetah::V2;
 
+// rot() of a LITERAL link-frame vector: a zero component costs nothing and a unit axis is (sin, cos) itself — hipcc does not
+// fold `0 * c` (NaN / inf semantics), and the hopper's capsules all lie along their link's z or x axis.  Same values as rot().
+template <typename R>
+__device__ __forceinline__ V2<R> rot_lit(R c, R s, double ax, double az) {
+    if (ax == 0.0 && az == 1.0) return V2<R>{s, c};
+    if (ax == 1.0 && az == 0.0) return V2<R>{c, -s};
+    if (ax == 0.0 && az == 0.0) return V2<R>{R(0), R(0)};
+    if (ax == 0.0) return V2<R>{(R)az * s, (R)az * c};
+    if (az == 0.0) return V2<R>{(R)ax * c, -((R)ax * s)};
+    return rot(c, s, (R)ax, (R)az);
+}
+
 // model constants from assets/hopper.xml (coordinate="global", degrees, inertiafromgeom, density 1000),
 // evaluated at compile time like the cheetah's (cheetah_model.h:kGeom)
 // the XML-level tables (hand-typed from hopper.xml; pinned to the file by tests/test_model_constants.py through
@@ -131,6 +143,22 @@ constexpr Model make_model(double dt) {
 
 // every dt-independent constant of the model, as compile-time immediates for the device code
 __device__ constexpr Model kGeom = make_model(0.002);
+
+// Impedance of a contact row.  hopper.xml:5 gives solimp (.8 .8 .01): dmin = dmax, so d(r) = 0.8 whatever the penetration — a
+// compile-time constant (the oracle's impedance() returns dmin + y * 0 = 0.8 for every finite r), and with it every contact
+// row's weight D = d / ((1 - d) diagApprox).  A non-finite r still poisons aref through K d r, as before.
+template <typename R>
+__device__ __forceinline__ R contact_impedance(R pos) {
+    if constexpr (kGeom.c_dmin == kGeom.c_dmax && kGeom.c_dmin > 1e-4 && kGeom.c_dmin < 0.9999) return (R)kGeom.c_dmin;
+    else return impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+}
+// imp / ((1 - imp) * diag): a literal when the impedance is one
+template <typename R>
+__device__ __forceinline__ R contact_weight(R imp, double diag) {
+    if constexpr (kGeom.c_dmin == kGeom.c_dmax && kGeom.c_dmin > 1e-4 && kGeom.c_dmin < 0.9999)
+        return (R)(kGeom.c_dmin / ((1.0 - kGeom.c_dmin) * diag));
+    else return div_r(imp, (R(1) - imp) * (R)diag);
+}
 
 // emei_model_constants (include/emei_hip.h), XML body order torso, thigh, leg, foot = chain order reversed
 inline int xml_constants(double* out) {
@@ -229,8 +257,8 @@ __device__ __forceinline__ bool capsule_pair(const R (&cs)[NL], const R (&sn)[NL
     constexpr int G1 = kPairGeom[PAIR][0], G2 = kPairGeom[PAIR][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
     constexpr CapsuleAxis c1 = capsule_axis(G1), c2 = capsule_axis(G2);
     constexpr double r1 = kGeom.radius[G1], r2 = kGeom.radius[G2], reach = r1 + r2 + kGeom.margin;
-    const V2<R> o1 = rot(cs[LA], sn[LA], (R)c1.cx, (R)c1.cz), a1 = rot(cs[LA], sn[LA], (R)c1.ax, (R)c1.az);
-    const V2<R> o2 = rot(cs[LB], sn[LB], (R)c2.cx, (R)c2.cz), a2 = rot(cs[LB], sn[LB], (R)c2.ax, (R)c2.az);
+    const V2<R> o1 = rot_lit(cs[LA], sn[LA], c1.cx, c1.cz), a1 = rot_lit(cs[LA], sn[LA], c1.ax, c1.az);
+    const V2<R> o2 = rot_lit(cs[LB], sn[LB], c2.cx, c2.cz), a2 = rot_lit(cs[LB], sn[LB], c2.ax, c2.az);
     const V2<R> p1 = {org[LA].x + o1.x, org[LA].z + o1.z}, p2 = {org[LB].x + o2.x, org[LB].z + o2.z};
     const V2<R> dif = {p1.x - p2.x, p1.z - p2.z};
     const R mb = -dot(a1, a2), u = -dot(a1, dif), w = dot(a2, dif);
@@ -441,7 +469,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
                 an = fma_r(Jz[i], z[i], an), at = fma_r(Jx[i], z[i], at);
             }
             const R pos = dist - (R)kGeom.margin;
-            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+            const R imp = contact_impedance(pos);
             const R k1 = div_r(R(1) - imp, imp);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - an, Ann + k1 * Ann);
             if (fn > R(0)) {
@@ -473,7 +501,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
             for (int i = LB; i < NV; ++i) yd[i] = y[i] * invd[i], Aii = fma_r(y[i], yd[i], Aii), acur = fma_r(y[i], z[i], acur);
             const R pos = dist - (R)kGeom.margin;
-            const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+            const R imp = contact_impedance(pos);
             const R fn = div_r(-(R)m.cB * vn - (R)m.cK * imp * pos - acur, Aii + div_r(R(1) - imp, imp) * Aii);
             if (fn > R(0)) {
 #pragma unroll
@@ -587,7 +615,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
         const int gi = pt / 2, L = L_TORSO - gi;
-        const R ez = fma_r((R)kGeom.geom_end[pt][1], cs[L], -((R)kGeom.geom_end[pt][0] * sn[L]));
+        const R ez = rot_lit(cs[L], sn[L], kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]).z;
         rows |= (org[L].z + ez - (R)kGeom.radius[gi] < (R)kGeom.margin) ? (1u << (3 + pt)) : 0u;
     }
     {  // bits 11-13: capsule pairs
@@ -682,7 +710,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     // pass of a wave) and their ~40 doubles fit the register file (386 VGPRs, no scratch): 25.7 vs 30.3 ms per
                     // 100 RK4 steps against recomputing per pass.  The cheetah (16 points, 2 in contact) does the opposite.
                     const R csl = cs[LNK], snl = sn[LNK];
-                    const V2<R> e = rot(csl, snl, (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const V2<R> e = rot_lit(csl, snl, kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
                     R Jx[NV], Jz[NV];
@@ -701,13 +729,13 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     constexpr double mu_c = kGeom.friction[gi];
                     const R mu = (R)mu_c;
                     const R pos = dist - (R)kGeom.margin;
-                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R imp = contact_impedance(pos);
                     const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
                     const R x1 = xn + xt, x2 = xn - xt;
                     const bool s1 = x1 < R(0), s2 = x2 < R(0), sy = xn < R(0);
                     flags |= ((s1 ? 1u : 0u) | (s2 ? 2u : 0u) | (sy ? 4u : 0u)) << (3 + 3 * pt);
                     if (s1 | s2 | sy) {
-                        const R Dw = div_r(imp, (R(1) - imp) * (R)(2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c)) * (R)kInvW.link[LNK]);
+                        const R Dw = contact_weight(imp, 2.0 * mu_c * mu_c * (1.0 + mu_c * mu_c) * kInvW.link[LNK]);
                         const R c1 = s1 ? R(1) : R(0), c2 = s2 ? R(1) : R(0), cy = sy ? R(2) : R(0);
                         const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
                         const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);
@@ -737,12 +765,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
                     for (int i = LB; i <= LA; ++i) vn = fma_r(J[i], u[i], vn), an = fma_r(J[i], a[i], an);
                     const R pos = dist - (R)kGeom.margin;
-                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R imp = contact_impedance(pos);
                     const R x = an + (R)m.cB * vn + (R)m.cK * imp * pos;
                     if (x < R(0)) {
                         flags |= 1u << (27 + P);
                         // frictionless row: diagApprox = the translational inverse weights of both bodies
-                        const R Dw = div_r(imp, (R(1) - imp) * (R)(kInvW.link[LA] + kInvW.link[LB]));
+                        const R Dw = contact_weight(imp, kInvW.link[LA] + kInvW.link[LB]);
                         const R t = Dw * x;
 #pragma unroll
                         for (int i = LB; i <= LA; ++i) {
@@ -793,7 +821,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             auto contact2 = [&](auto pt_c) __attribute__((always_inline)) {
                 constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
                 if (rows & (1u << (3 + pt))) {
-                    const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
+                    const V2<R> e = rot_lit(cs[LNK], sn[LNK], kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
                     R Jx[NV], Jz[NV];
@@ -811,7 +839,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     }
                     const R mu = (R)kGeom.friction[gi];
                     const R pos = dist - (R)kGeom.margin;
-                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R imp = contact_impedance(pos);
                     const R xn = an + (R)m.cB * vn + (R)m.cK * imp * pos, xt = mu * (at + (R)m.cB * vt);
                     again |= ((xn + xt < R(0) ? 1u : 0u) | (xn - xt < R(0) ? 2u : 0u) | (xn < R(0) ? 4u : 0u)) << (3 + 3 * pt);
                 }
@@ -830,7 +858,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
                     for (int i = LB; i <= LA; ++i) vn = fma_r(J[i], u[i], vn), an = fma_r(J[i], a[i], an);
                     const R pos = dist - (R)kGeom.margin;
-                    const R imp = impedance(pos, (R)kGeom.c_dmin, (R)kGeom.c_dmax, (R)(1.0 / kGeom.c_width));
+                    const R imp = contact_impedance(pos);
                     again |= (an + (R)m.cB * vn + (R)m.cK * imp * pos < R(0)) ? (1u << (27 + P)) : 0u;
                 }
             };
