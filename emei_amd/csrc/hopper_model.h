@@ -713,16 +713,18 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const V2<R> e = rot_lit(csl, snl, kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
-                    R Jx[NV], Jz[NV];
+                    // Jacobian rows J_t = Jx, J_n = Jz: the link entries LNK .. torso; the root translation's are the literals
+                    // Jx[P_X] = Jz[P_Z] = 1, Jx[P_Z] = Jz[P_X] = 0, written out below as plain additions (hipcc keeps `0 * u` and
+                    // `1 * u` as multiplications: ~20 of a block's ~105 instructions per pass)
+                    R Jx[NL], Jz[NL];
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
-                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    for (int i = 0; i < NL; ++i) Jx[i] = R(0), Jz[i] = R(0);
                     Jx[LNK] = r.z, Jz[LNK] = -r.x;
 #pragma unroll
                     for (int b = LNK + 1; b < NL; ++b) Jx[b] = D[b].z, Jz[b] = -D[b].x;
-                    R vn = R(0), vt = R(0), an = R(0), at = R(0);
+                    R vn = u[P_Z], vt = u[P_X], an = a[P_Z], at = a[P_X];
 #pragma unroll
-                    for (int i = LNK; i < NV; ++i) {
+                    for (int i = LNK; i < NL; ++i) {
                         vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
                         an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
                     }
@@ -740,12 +742,15 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                         const R gn = Dw * (c1 * x1 + c2 * x2 + cy * xn), gt = Dw * mu * (c1 * x1 - c2 * x2);
                         const R wnn = Dw * (c1 + c2 + cy), wtt = Dw * mu * mu * (c1 + c2), wnt = Dw * mu * (c1 - c2);
 #pragma unroll
-                        for (int i = LNK; i < NV; ++i) {
+                        for (int i = LNK; i < NL; ++i) {
                             gr[i] = fma_r(Jz[i], gn, fma_r(Jx[i], gt, gr[i]));
                             const R ux = fma_r(wtt, Jx[i], wnt * Jz[i]), uz = fma_r(wnt, Jx[i], wnn * Jz[i]);
 #pragma unroll
                             for (int j = LNK; j <= i; ++j) A[i][j] = fma_r(ux, Jx[j], fma_r(uz, Jz[j], A[i][j]));
+                            A[P_X][i] += ux, A[P_Z][i] += uz;  // rows of the root translation: J' W J against the unit columns
                         }
+                        gr[P_X] += gt, gr[P_Z] += gn;
+                        A[P_X][P_X] += wtt, A[P_Z][P_X] += wnt, A[P_Z][P_Z] += wnn;
                     }
                 }
             };
@@ -824,16 +829,15 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const V2<R> e = rot_lit(cs[LNK], sn[LNK], kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
                     const V2<R> r = {e.x, R(0.5) * dist - org[LNK].z};
-                    R Jx[NV], Jz[NV];
+                    R Jx[NL], Jz[NL];  // as in the pass above: link entries; the root translation's are literals
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) Jx[i] = R(0), Jz[i] = R(0);
-                    Jx[P_X] = R(1), Jz[P_Z] = R(1);
+                    for (int i = 0; i < NL; ++i) Jx[i] = R(0), Jz[i] = R(0);
                     Jx[LNK] = r.z, Jz[LNK] = -r.x;
 #pragma unroll
                     for (int b = LNK + 1; b < NL; ++b) Jx[b] = D[b].z, Jz[b] = -D[b].x;
-                    R vn = R(0), vt = R(0), an = R(0), at = R(0);
+                    R vn = u[P_Z], vt = u[P_X], an = a[P_Z], at = a[P_X];
 #pragma unroll
-                    for (int i = LNK; i < NV; ++i) {
+                    for (int i = LNK; i < NL; ++i) {
                         vn = fma_r(Jz[i], u[i], vn), vt = fma_r(Jx[i], u[i], vt);
                         an = fma_r(Jz[i], a[i], an), at = fma_r(Jx[i], a[i], at);
                     }
