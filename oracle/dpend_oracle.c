@@ -27,6 +27,7 @@
 
 typedef struct {
     double mc, mp, Ip, lc, L1, gx, gz, gear, x_lo, x_hi, margin, invw, tc, dmin, dmax, width;
+    double ctrl_lo, ctrl_hi; /* motor ctrlrange (xml:45): the clamp dp_accel applies */
 } dp_model_t;
 
 static double capsule_mass(double rho, double r, double half) { return rho * (M_PI * r * r * 2 * half + 4.0 / 3.0 * M_PI * r * r * r); }
@@ -75,7 +76,7 @@ EXPORT void dpend_oracle_model(dp_model_t* m, double dt) {
     m->Ip = capsule_inertia_perp(rho, 0.045, 0.3);
     m->lc = 0.3, m->L1 = 0.6;                     /* xml:35-36 */
     m->gx = 1e-5, m->gz = 9.81;                   /* xml:26 */
-    m->gear = 500.0;                              /* xml:45 */
+    m->gear = 500.0, m->ctrl_lo = -1, m->ctrl_hi = 1; /* xml:45 */
     m->x_lo = -3, m->x_hi = 3, m->margin = 0.01;  /* xml:31 */
     m->tc = 0.02 < 2 * dt ? 2 * dt : 0.02;        /* default solref timeconst, refsafe */
     m->dmin = 0.9, m->dmax = 0.95, m->width = 0.001;
@@ -89,7 +90,7 @@ EXPORT void dpend_oracle_model(dp_model_t* m, double dt) {
 EXPORT int dpend_oracle_xml_constants(double* out) {
     dp_model_t m;
     dpend_oracle_model(&m, 0.002);
-    const double v[17] = {m.gx, m.gz, m.mc, m.mp, m.Ip, m.lc, m.L1, m.gear, -1.0 /* ctrl clamp of dp_accel */, 1.0, m.x_lo, m.x_hi,
+    const double v[17] = {m.gx, m.gz, m.mc, m.mp, m.Ip, m.lc, m.L1, m.gear, m.ctrl_lo, m.ctrl_hi /* the fields dp_accel clamps with */, m.x_lo, m.x_hi,
                           m.margin, m.tc /* at dt = 0.002: the unclamped default */, m.dmin, m.dmax, m.width};
     memcpy(out, v, sizeof(v));
     return 17;
@@ -110,7 +111,7 @@ static void dp_accel(const void* ctx, double dt, double hd, const double* q, con
     (void)dt, (void)hd;
     double M[3][3], bias[3], rhs[3];
     dp_dynamics(m, off, q, v, M, bias);
-    double ctrl = u < -1 ? -1 : (u > 1 ? 1 : u);
+    double ctrl = u < m->ctrl_lo ? m->ctrl_lo : (u > m->ctrl_hi ? m->ctrl_hi : u);
     rhs[0] = m->gear * ctrl - bias[0], rhs[1] = -bias[1], rhs[2] = -bias[2];
     solve3(M, rhs, acc);
     double dist = 0, J = 0;

@@ -78,6 +78,7 @@ typedef struct {
     int limited[NV];
     int act_dof[NU];
     double gear[NU];
+    double ctrl_lo, ctrl_hi; /* motors: ctrllimited, ctrlrange (half_cheetah.xml:88-95, hopper.xml:37-39): the clamp of smooth_terms */
     double gravity;
     /* solref / solimp: contacts and joint limits */
     double c_tc, c_dr, c_dmin, c_dmax, c_width;
@@ -163,6 +164,7 @@ EXPORT void cheetah_oracle_model(planar_model_t* m) {
     }
     for (int k = 0; k < 8; ++k) m->geom_friction[k] = 0.4; /* default geom friction .4 (xml:38), floor the same */
     m->gravity = 9.81;
+    m->ctrl_lo = -1, m->ctrl_hi = 1;
     m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.0, m->c_dmax = 0.8, m->c_width = 0.01;
     m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.0, m->l_dmax = 0.8, m->l_width = 0.03;
     set_invweights(m);
@@ -207,6 +209,7 @@ EXPORT void hopper_oracle_model(planar_model_t* m) {
     m->contact_margin = 0.001;
     m->self_collide = 1; /* :5; the cheetah's geoms have conaffinity 0 (half_cheetah.xml:39): floor only */
     m->gravity = 9.81;
+    m->ctrl_lo = -1, m->ctrl_hi = 1;
     m->c_tc = 0.02, m->c_dr = 1, m->c_dmin = 0.8, m->c_dmax = 0.8, m->c_width = 0.01;
     m->l_tc = 0.02, m->l_dr = 1, m->l_dmin = 0.9, m->l_dmax = 0.95, m->l_width = 0.001; /* MuJoCo joint defaults */
     set_invweights(m);
@@ -238,7 +241,7 @@ EXPORT int planar_oracle_xml_constants(int body, double* out) {
     out[n++] = m.contact_margin;
     out[n++] = m.c_tc, out[n++] = m.c_dmin, out[n++] = m.c_dmax, out[n++] = m.c_width;
     out[n++] = m.l_tc, out[n++] = m.l_dmin, out[n++] = m.l_dmax, out[n++] = m.l_width;
-    out[n++] = -1.0, out[n++] = 1.0; /* the ctrl clamp of smooth_terms / planar_accel_sweep1 */
+    out[n++] = m.ctrl_lo, out[n++] = m.ctrl_hi; /* the fields smooth_terms / planar_accel_sweep1 clamp with */
     out[n++] = m.z_ref, out[n++] = m.hinge_sign[m.nb - 1];
     return n;
 }
@@ -354,7 +357,7 @@ static void smooth_terms(const planar_model_t* m, const kin_t* k, const double* 
         M[i][i] += m->armature[i];
     }
     for (int a = 0; a < m->nu; ++a) {
-        double c = ctrl[a] < -1 ? -1 : (ctrl[a] > 1 ? 1 : ctrl[a]); /* ctrllimited, ctrlrange +-1 */
+        double c = ctrl[a] < m->ctrl_lo ? m->ctrl_lo : (ctrl[a] > m->ctrl_hi ? m->ctrl_hi : ctrl[a]); /* ctrllimited */
         f[m->act_dof[a]] += m->gear[a] * c;
     }
 }
@@ -676,7 +679,7 @@ static void planar_accel_sweep1(const void* ctx, double dt, double hd, const dou
         M[i][i] += m->armature[i] + hd * m->damping[i];                  /* Euler with implicit damping: M + h D */
     }
     for (int a = 0; a < m->nu; ++a) {
-        double c = ctrl[a] < -1 ? -1 : (ctrl[a] > 1 ? 1 : ctrl[a]); /* ctrllimited, ctrlrange +-1 */
+        double c = ctrl[a] < m->ctrl_lo ? m->ctrl_lo : (ctrl[a] > m->ctrl_hi ? m->ctrl_hi : ctrl[a]); /* ctrllimited */
         f[m->act_dof[a]] += m->gear[a] * c;
     }
     ldl_factor(nv, M);

@@ -155,14 +155,28 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from isa_scan import exec_restore_hazards  # noqa: E402
 
 
+# Joins that re-store a spill slot which ALSO has an unmasked store elsewhere are downgraded to notes by the scanner (hipcc
+# re-storing a split live range).  That downgrade does not prove the slot already holds the value, so every such site is
+# reviewed by hand and pinned here: {kernel name fragment: sites}.  A new site — or one that moved to another kernel — fails
+# the test until its disassembly has been read.
+#   HopperBody<float, 0>, RK4: 12 stores to consecutive AGPRs at the tail of the auto-reset then-block, writing the NEW state
+#   under the done mask in front of the restore; the reload reads what the unmasked path stored for the other lanes.  Legitimate.
+REVIEWED_RESTORE_NOTES = {"body_rollout_kernelINS_10HopperBodyIfLi0EEELb1EEE": 1}
+
+
 def test_no_vector_instruction_in_front_of_an_exec_restore(functions):
     """Every kernel of the shipped library: nothing EXEC-dependent sits between the start of a join block and its EXEC restore."""
-    bad = {}
+    bad, noted = {}, {}
     for name, ins in functions.items():
-        h = exec_restore_hazards(ins)
+        notes = []
+        h = exec_restore_hazards(ins, notes)
         if h:
             bad[name] = h[:3]
+        if notes:
+            noted[name] = len(notes)
     assert not bad, bad
+    unreviewed = {n: c for n, c in noted.items() if not any(k in n and c == v for k, v in REVIEWED_RESTORE_NOTES.items())}
+    assert not unreviewed, f"re-store joins nobody has reviewed (tools/isa_scan.py prints them): {unreviewed}"
 
 
 def _listing(text):
