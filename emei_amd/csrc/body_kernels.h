@@ -219,22 +219,39 @@ struct BodyArgs {
 // Body::kMinWavesPerEU = 2 caps the kernel at 256 registers so that two waves share a SIMD (measured per
 // body: it pays for the Hopper, whose RK4 working set then spills little; the cheetah spills 660 B/lane
 // to scratch at that cap and is faster with one resident wave and AGPRs as spill space)
+// Threads per block of the rollout kernel.  The bodies that run at ONE wave per SIMD (the register file is the limit) use
+// one-wave blocks: the dispatcher then refills a SIMD as soon as its wave ends, instead of a CU waiting for the slowest of a
+// four-wave block (131 072 envs = two rounds of 1024 waves: with 256-thread blocks a CU runs exactly two blocks back to back).
+// A/B on one box, 256 -> 64 threads: cheetah 8.06 -> 7.67 ms per 100 steps, Hopper RK4 26.46 -> 25.99, Euler 8.19 -> 8.11, the
+// double pendulum unchanged; results bit-identical (a lane's arithmetic does not depend on its block).  -DEMEI_BODY_BLOCK=n
+// overrides it for experiments.
+template <class Body>
+__host__ __device__ constexpr int rollout_block() {
+#ifdef EMEI_BODY_BLOCK
+    return EMEI_BODY_BLOCK;
+#else
+    return Body::kMinWavesPerEU == 1 ? kWave : kBlock;
+#endif
+}
+
 template <class Body, bool RK4>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEU)))
+__global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEU)))
     body_rollout_kernel(const BodyArgs<Body> a) {
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
+    constexpr int kBlock = rollout_block<Body>();  // shadows the library-wide 256 inside this kernel
     constexpr int kWaves = kBlock / kWave;
     constexpr int kActVec = (kWave * NA + 3) / 4, kObsVec = (kWave * NO + 3) / 4;  // 16-byte vectors per wave block
     constexpr int kActIt = (kActVec + kWave - 1) / kWave, kObsIt = (kObsVec + kWave - 1) / kWave;
     __shared__ __attribute__((aligned(16))) float act_s[kWaves][kActIt * kWave * 4];
     __shared__ __attribute__((aligned(16))) float obs_s[kWaves][kObsIt * kWave * 4];
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, a.trig);  // every thread reaches the barrier: inactive lanes stay in the kernel
+    stage_trig_table<kBlock>(trig_s, a.trig);  // every thread reaches the barrier: inactive lanes stay in the kernel
     TrigCtx trig;
     trig.tab = trig_s;
     __shared__ R scratch_s[(Body::kScratchPerLane > 0 ? Body::kScratchPerLane : 1) * (Body::kScratchPerLane > 0 ? kBlock : 1)];
     if constexpr (Body::kScratchPerLane > 0) trig.scratch = scratch_s;
+    trig.scratch_stride = kBlock;
     trig.cap_hits = a.cap_hits;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -506,6 +523,7 @@ static int launch_body(const BodyLaunch& L) {
     using R = typename Body::real;
     const typename Body::Model m = Body::make_model(L.dt, L.env_params);
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
+    dim3 rgrid((unsigned)((L.n + rollout_block<Body>() - 1) / rollout_block<Body>()));  // the rollout kernel's own block size
     switch (L.op) {
         case BODY_OP_ROLLOUT: {
             BodyArgs<Body> a;
@@ -517,9 +535,9 @@ static int launch_body(const BodyLaunch& L) {
             a.trig = (const SinCosEntry*)L.trig;
             a.cap_hits = L.cap_hits;
             if (L.integrator == EMEI_INTEG_RK4)
-                hipLaunchKernelGGL((body_rollout_kernel<Body, true>), grid, dim3(kBlock), 0, L.stream, a);
+                hipLaunchKernelGGL((body_rollout_kernel<Body, true>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
             else
-                hipLaunchKernelGGL((body_rollout_kernel<Body, false>), grid, dim3(kBlock), 0, L.stream, a);
+                hipLaunchKernelGGL((body_rollout_kernel<Body, false>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
             if (L.selected) *L.selected = L.integrator == EMEI_INTEG_RK4 ? EMEI_KERNEL_BODY_RK4 : EMEI_KERNEL_BODY;
             break;
         }

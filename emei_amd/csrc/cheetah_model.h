@@ -792,8 +792,8 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             EMEI_STAT_LANE(22);
             EMEI_STAT_WAVE(23);
             R* const sl = (R*)trig.scratch + threadIdx.x;
-            auto put = [&](int sidx, int fld, R val) __attribute__((always_inline)) { sl[(sidx * kSlotFields + fld) * kBlock] = val; };
-            auto get = [&](int sidx, int fld) __attribute__((always_inline)) { return sl[(sidx * kSlotFields + fld) * kBlock]; };
+            auto put = [&](int sidx, int fld, R val) __attribute__((always_inline)) { sl[(sidx * kSlotFields + fld) * trig.scratch_stride] = val; };
+            auto get = [&](int sidx, int fld) __attribute__((always_inline)) { return sl[(sidx * kSlotFields + fld) * trig.scratch_stride]; };
             const R mu = (R)kGeom.friction;
             int slot = 0;
             // a violated joint limit is a slot with one direction: J = +-(e_C - e_P), no tangent, mu = 0 and D / 4 (with

@@ -150,8 +150,9 @@ struct TrigCtx {
     double c3, c4;  // -1/6, 1/24
     uint32_t lds_base;  // byte address of `tab` in LDS, wave-uniform (an SGPR)
     // per-block LDS scratch of the body kernels (Body::kScratchPerLane elements of Body::real per lane, lane-interleaved:
-    // element e of this lane at scratch[e * kBlock + threadIdx.x]); null where a kernel provides none
+    // element e of this lane at scratch[e * scratch_stride + threadIdx.x]); null where a kernel provides none
     void* scratch = nullptr;
+    int scratch_stride = kBlock;  // threads per block of the kernel that owns the scratch (a compile-time value after inlining)
     // handle counter of Newton solves that ended at the iteration cap without meeting their stopping rule (emei_get_solver_cap_hits);
     // null in the stateless kernels
     unsigned long long* cap_hits = nullptr;
@@ -252,11 +253,15 @@ __device__ __forceinline__ void sincos_ctx(const TrigCtx& t, float x, float& s, 
 // (callers stage the table before any early return)
 // `scale`: an env whose dynamics only ever use m * sin and m * cos stages the table pre-multiplied (InvPend: the
 // pole's mass moment) and saves the two products per substep; 1 = the plain table.
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src, double scale = 1.0) {
-    static_assert(kBlock == kTrigTableSize, "one table entry per thread");
-    SinCosEntry e = src[threadIdx.x];
-    if (scale != 1.0) e.s *= scale, e.c *= scale;
-    lds[threadIdx.x] = e;
+    static_assert(kTrigTableSize % BLOCK == 0, "every thread copies the same number of entries");
+#pragma unroll
+    for (int k = 0; k < kTrigTableSize / BLOCK; ++k) {
+        SinCosEntry e = src[k * BLOCK + threadIdx.x];
+        if (scale != 1.0) e.s *= scale, e.c *= scale;
+        lds[k * BLOCK + threadIdx.x] = e;
+    }
     __syncthreads();
 }
 
