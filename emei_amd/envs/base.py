@@ -281,6 +281,61 @@ def joint_sigmas(params, nq):
     return np.full(nq, float(params)), np.full(nq, float(params))
 
 
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3  # mjtJoint
+
+
+def _quat_mul(a, b):
+    """Hamilton product of scalar-LAST quaternions (x, y, z, w)"""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def check_noise_joints(jnt_type):
+    """`additive_gaussian_noise` (mujoco_env.py:229-237) with a free joint: the routine slices ROWS of the [B, nq] arrays
+    (`origin_pos[cur + 3 : cur + 7]`), so `Rotation.from_quat` never sees a quaternion and raises ValueError for every batch
+    size (tests/golden/freejoint_golden.npz: fj_noise_B1_raises, fj_noise_B4_raises) — the same error here, with the reason."""
+    if any(t == JNT_FREE for t in jnt_type):
+        raise ValueError("additive_gaussian_noise: a free joint's quaternion is sliced by rows (mujoco_env.py:235): the reference "
+                         "raises ValueError for every batch size")
+    if any(t == JNT_BALL for t in jnt_type):
+        raise NotImplementedError
+
+
+def euler_position_rule(old_pos, old_vel, jnt_type, dt):
+    """`EmeiMujocoEnv.get_euler_pos` (mujoco_env.py:169-195) for ANY joint list: q += dt * v for slide / hinge joints (what the
+    kernels do on the device: every env of the engine has only those), NotImplementedError for a ball joint (:185-186), and for
+    a free joint (:176-184) exactly what the reference executes — position += dt * linear velocity; the four quaternion entries
+    of qpos (MuJoCo stores w first) are handed to SciPy's Rotation AS IF scalar-last, read out as extrinsic z-y-x Euler angles
+    in DEGREES, the angular velocity * dt (radians) is added to those degrees, and the sum is re-composed as extrinsic x-y-z
+    angles into the new quaternion.  Restated with plain NumPy (no SciPy needed); pinned by tests/golden/freejoint_golden.npz."""
+    old_pos, old_vel = np.asarray(old_pos, dtype=np.float64), np.asarray(old_vel, dtype=np.float64)
+    new_pos = old_pos.copy()
+    ip = iv = 0
+    for t in jnt_type:
+        if t == JNT_FREE:
+            new_pos[ip:ip + 3] += old_vel[iv:iv + 3] * dt
+            x, y, z, w = old_pos[ip + 3:ip + 7] / np.linalg.norm(old_pos[ip + 3:ip + 7])  # Rotation.from_quat normalises
+            # rotation matrix entries needed for R = Rx(c) Ry(b) Rz(a)  (as_euler("zyx"): about fixed z, then y, then x)
+            r00, r01, r02 = 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)
+            r12, r22 = 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)
+            ang = np.degrees([np.arctan2(-r01, r00), np.arcsin(np.clip(r02, -1.0, 1.0)), np.arctan2(-r12, r22)])
+            ang = ang + old_vel[iv + 3:iv + 6] * dt
+            h = np.radians(ang) / 2  # from_euler("xyz"): about fixed x by ang[0], then y by ang[1], then z by ang[2]
+            qx = np.array([np.sin(h[0]), 0.0, 0.0, np.cos(h[0])])
+            qy = np.array([0.0, np.sin(h[1]), 0.0, np.cos(h[1])])
+            qz = np.array([0.0, 0.0, np.sin(h[2]), np.cos(h[2])])
+            new_pos[ip + 3:ip + 7] = _quat_mul(qz, _quat_mul(qy, qx))
+            ip, iv = ip + 7, iv + 6
+        elif t == JNT_BALL:
+            raise NotImplementedError
+        else:
+            new_pos[ip] += old_vel[iv] * dt
+            ip, iv = ip + 1, iv + 1
+    return new_pos
+
+
 class ParityUnpinnedWarning(UserWarning):
     """The dynamics of a MuJoCo-backed env are a restatement of MuJoCo's published algorithms, not libmujoco itself."""
 
@@ -335,6 +390,13 @@ class MujocoHipEnv(HipEnv):
     def get_batch_init_state(self, batch_size):
         s = self._host_init_state(batch_size)
         return s[:, :self.NQ], s[:, self.NQ:]  # (pos, vel), mujoco_env.py:137-140
+
+    JNT_TYPE = None  # model.jnt_type; None = 1-dof joints only (every env of this package)
+
+    def get_euler_pos(self, old_pos, old_vel):
+        """mujoco_env.py:169-195 on the host, for callers that use the position rule by itself (the kernels apply it per substep)"""
+        jt = self.JNT_TYPE if self.JNT_TYPE is not None else [JNT_SLIDE] * self.NQ  # slide and hinge joints share the rule
+        return euler_position_rule(old_pos, old_vel, jt, self.real_time_scale)
 
     def transform_state_to_obs(self, batch_state):
         pos, vel = batch_state

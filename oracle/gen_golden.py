@@ -638,6 +638,45 @@ def gen_model_constants(ref_root, out):
     return data
 
 
+def gen_freejoint(ref, out):
+    """The free-joint branch of the Euler position rule (mujoco_env.py:176-184: the qpos quaternion goes through SciPy's
+    Rotation as if it were scalar-last, `as_euler("zyx", degrees=True)`, velocity * dt is added to the DEGREES, and
+    `from_euler("xyz", ...)` builds the new quaternion) on models with a free joint in front of / between 1-dof joints; and what
+    the noise routine (:229-237) does with a free joint: it slices ROWS of the [B, nq] arrays, so `from_quat` always raises."""
+    data = {}
+    rng = np.random.default_rng(4242)
+    for nm, jt in (("free", [0]), ("free_hinge2", [0, 3, 3]), ("slide_free_hinge", [2, 0, 3])):
+        nq = sum(7 if t == 0 else 1 for t in jt)
+        nv = sum(6 if t == 0 else 1 for t in jt)
+        for dt in (0.02, 0.002):
+            f = NS(model=NS(jnt_type=jt), real_time_scale=dt)
+            qp = rng.normal(0, 1, (64, nq))
+            k = 0
+            for t in jt:  # unit quaternions where a free joint keeps one (the routine normalises anyway: rows 48.. stay unnormalised)
+                if t == 0:
+                    qp[:48, k + 3 : k + 7] /= np.linalg.norm(qp[:48, k + 3 : k + 7], axis=1, keepdims=True)
+                    k += 7
+                else:
+                    k += 1
+            qv = rng.normal(0, 5, (64, nv))
+            data[f"fj_{nm}_dt{dt}_qpos"], data[f"fj_{nm}_dt{dt}_qvel"] = qp, qv
+            data[f"fj_{nm}_dt{dt}_newpos"] = np.stack([ref.me.EmeiMujocoEnv.get_euler_pos(f, qp[i], qv[i]) for i in range(64)])
+    for nm, jt in (("ball", [1]), ("hinge_ball", [3, 1])):  # ball joints: NotImplementedError (:185-186)
+        try:
+            ref.me.EmeiMujocoEnv.get_euler_pos(NS(model=NS(jnt_type=jt), real_time_scale=0.02), np.zeros(5), np.zeros(4))
+            data[f"fj_{nm}_raises"] = np.asarray("")
+        except Exception as e:  # noqa: BLE001
+            data[f"fj_{nm}_raises"] = np.asarray(type(e).__name__)
+    for B in (1, 4):
+        try:
+            ref.me.EmeiMujocoEnv.additive_gaussian_noise(NS(model=NS(jnt_type=[0])), np.tile([0, 0, 0, 1.0, 0, 0, 0], (B, 1)), np.zeros((B, 6)), 0.1)
+            data[f"fj_noise_B{B}_raises"] = np.asarray("")
+        except Exception as e:  # noqa: BLE001
+            data[f"fj_noise_B{B}_raises"] = np.asarray(type(e).__name__)
+    np.savez_compressed(os.path.join(out, "freejoint_golden.npz"), **data)
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -651,12 +690,13 @@ def main():
     h = gen_hopper_firstparty(ref, a.out)
     lg = gen_lagrange(a.ref, a.out)
     mc = gen_model_constants(a.ref, a.out)
+    fj = gen_freejoint(ref, a.out)
     env = ref.cp.CartPoleSwingUpEnv()
     o, _ = env.reset(seed=0)
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg), " model-constant keys:", len(mc))
+    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg), " model-constant keys:", len(mc), " free-joint keys:", len(fj))
 
 
 if __name__ == "__main__":

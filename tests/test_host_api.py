@@ -238,3 +238,30 @@ def test_mujoco_backed_envs_warn_that_parity_is_unpinned():
         emei_amd.CartPoleSwingUpEnv()  # first-party dynamics, pinned: no warning
     got = [x for x in w if issubclass(x.category, ParityUnpinnedWarning)]
     assert len(got) == 1 and "libmujoco" in str(got[0].message)
+
+
+def test_free_joint_branch_of_the_euler_position_rule_vs_golden():
+    """mujoco_env.py:176-184 (VERDICT r03 missing #5): no env on the path has a free joint, so this is host code only — the
+    reference's composition of SciPy rotations (scalar-first qpos read as scalar-last, degrees + radians, zyx out / xyz in),
+    restated in NumPy, against vectors made by the reference itself (oracle/gen_golden.py:gen_freejoint)."""
+    import os
+
+    from emei_amd.envs.base import check_noise_joints, euler_position_rule
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "freejoint_golden.npz"))
+    for nm, jt in (("free", [0]), ("free_hinge2", [0, 3, 3]), ("slide_free_hinge", [2, 0, 3])):
+        for dt in (0.02, 0.002):
+            qp, qv, want = g[f"fj_{nm}_dt{dt}_qpos"], g[f"fj_{nm}_dt{dt}_qvel"], g[f"fj_{nm}_dt{dt}_newpos"]
+            got = np.stack([euler_position_rule(qp[i], qv[i], jt, dt) for i in range(len(qp))])
+            assert np.abs(got - want).max() <= 1e-13, (nm, dt)
+            assert (np.abs(np.linalg.norm(got[:, jt.index(0) + 3: jt.index(0) + 7], axis=1) - 1) < 1e-14).all()  # unit quaternions out
+    assert str(g["fj_ball_raises"]) == str(g["fj_hinge_ball_raises"]) == "NotImplementedError"
+    with pytest.raises(NotImplementedError):
+        euler_position_rule(np.zeros(5), np.zeros(4), [3, 1], 0.02)
+    assert str(g["fj_noise_B1_raises"]) == str(g["fj_noise_B4_raises"]) == "ValueError"
+    with pytest.raises(ValueError):
+        check_noise_joints([0, 3])
+    # the envs of this package: 1-dof joints, q += dt v (the rule the kernels apply per substep)
+    env = emei_amd.HopperRunningEnv()
+    q, v = np.arange(6.0), np.ones(6)
+    assert np.array_equal(env.get_euler_pos(q, v), q + env.real_time_scale * v)
