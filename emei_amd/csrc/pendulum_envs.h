@@ -41,6 +41,11 @@ struct CartPole {
     static constexpr int kActDim = 1;
     struct Carry {
         R sn, cs;
+        // float32(x_dot), float32(theta_dot) of the CURRENT state: the position update multiplies exactly these by float32(dt)
+        // (base_control.py:164) and the observation of the previous step stored exactly these — converted once, at the end of the
+        // substep that produced them, instead of once for the observation and again for the next update (2 of a step's 74
+        // vector instructions)
+        float xd32, td32;
         TrigCtx trig;
     };
     using Action = R;  // force / total_mass
@@ -75,7 +80,13 @@ struct CartPole {
 
     __device__ __forceinline__ static void prime(const R s[4], Carry& c, const Params&) {
         sincos_ctx(c.trig, s[2], c.sn, c.cs);
+        after_reset(s, c);
     }
+    // the part of the carry that is not trigonometry: refreshed wherever the state is replaced (reset from a spare state)
+    __device__ __forceinline__ static void after_reset(const R s[4], Carry& c) { c.xd32 = (float)s[1], c.td32 = (float)s[3]; }
+    // ... kept with a spare initial state, so that a reset copies it (two 32-bit selects) instead of converting again
+    __device__ __forceinline__ static void save_extra(const Carry& c, float& e0, float& e1) { e0 = c.xd32, e1 = c.td32; }
+    __device__ __forceinline__ static void load_extra(Carry& c, float e0, float e1) { c.xd32 = e0, c.td32 = e1; }
 
     // One explicit-Euler substep: cartpole.py:48-60 (_dsdt) + base_control.py:162-164.
     //   temp      = (force + pml*thd^2*sin) / M
@@ -90,11 +101,11 @@ struct CartPole {
         const R B = R(0.5 * 0.1 / 1.1);        // length * mass_pole / total_mass
         const R L43 = R(0.5 * 4.0 / 3.0);      // length * 4/3
         const R gravity = R(9.8);
-        const R x_dot = s[1], theta_dot = s[3];
+        const R theta_dot = s[3];
         // theta advances with the OLD theta_dot only, so its new sin/cos does not wait for the
         // accelerations: issue it first and let it overlap the dynamics below
-        s[0] += (R)__fmul_rn((float)x_dot, p.dt32);
-        s[2] += (R)__fmul_rn((float)theta_dot, p.dt32);
+        s[0] += (R)__fmul_rn(c.xd32, p.dt32);
+        s[2] += (R)__fmul_rn(c.td32, p.dt32);
         R sn = c.sn, cs = c.cs;
         auto pending = sincos_begin_ctx(c.trig, s[2]);  // table read in flight under the dynamics
         sincos_pin(pending, sn, cs);
@@ -107,6 +118,7 @@ struct CartPole {
         // (base_control.py:164, weak-scalar promotion), accumulated in R (float64 in the reference)
         s[1] += (R)__fmul_rn((float)x_acc, p.dt32);
         s[3] += (R)__fmul_rn((float)theta_acc, p.dt32);
+        c.xd32 = (float)s[1], c.td32 = (float)s[3];  // the same conversions the observation store makes: one instruction each
         sincos_end_ctx(pending, x_acc, theta_acc, c.sn, c.cs);
         sincos_post_ctx(s[2], c.sn, c.cs);
     }
@@ -314,6 +326,9 @@ struct InvPend {
         sincos_ctx(c.trig, s[1] + (R)km().phi_off, c.sn, c.cs);
         if (!kF64) c.sn *= (R)km().mpr, c.cs *= (R)km().mpr;
     }
+    __device__ __forceinline__ static void after_reset(const R[4], Carry&) {}  // the carry is trigonometry only
+    __device__ __forceinline__ static void save_extra(const Carry&, float&, float&) {}
+    __device__ __forceinline__ static void load_extra(Carry&, float, float) {}
 
     // One substep.  P = mpr sin(phi), Q = mpr cos(phi) (= M12) at the OLD angle, gu = gear * ctrl:
     //   f1 = gu + P omega^2,  f2 = g P,  det = M11 M22 - Q^2

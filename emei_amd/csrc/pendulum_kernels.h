@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     // then for every lane without one at once (the first reset of a wave draws all 64).  The draw is a
     // pure function of (seed, global env, episode), so results do not depend on when it is computed.
     R sp[4] = {R(0), R(0), R(0), R(0)}, sp_sn = R(0), sp_cs = R(0);  // dead outside the redraw when the spare lives in LDS
+    float sp_e0 = 0.f, sp_e1 = 0.f;  // the non-trigonometric part of the spare's carry (Env::save_extra / load_extra)
     const unsigned long long reset_mask = auto_reset ? ~0ull : 0ull;
     // which lanes hold a spare: a wave-uniform 64-bit mask in scalar registers (ballot results and scalar logic only), so
     // that the bookkeeping of a reset costs no vector instruction; `inverse_ballot` turns it back into a lane predicate
@@ -260,6 +261,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                         spare_s[wv][3][lane] = sp[3], spare_s[wv][4][lane] = sc.sn, spare_s[wv][5][lane] = sc.cs;
                     } else {
                         sp_sn = sc.sn, sp_cs = sc.cs;
+                        Env::save_extra(sc, sp_e0, sp_e1);
                     }
                 }
                 spare_mask = ~0ull;
@@ -274,6 +276,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
 #pragma unroll
                     for (int k = 0; k < 4; ++k) s[k] = sp[k];
                     c.sn = sp_sn, c.cs = sp_cs;
+                    Env::load_extra(c, sp_e0, sp_e1);
                 }
             }
             spare_mask &= ~done_mask;
