@@ -18,9 +18,20 @@ for body, name, nv, nu, step in (("cheetah", "HalfCheetahRunning", 9, 6, O.cheet
     q = rng.normal(0, 0.25, (n, nv))
     q[:, 1] = rng.uniform(-0.45, 0.3, n) if body == "cheetah" else 1.25 + rng.uniform(-0.4, 0.1, n)
     q[: n // 4, 3:] = rng.uniform(-1.5, 1.5, (n // 4, nv - 3))
+    if body == "hopper":  # round 4: a quarter with the leg folded towards its -150 degree limits, in the air and on the ground: the
+        k = n // 4        # capsule-capsule rows (torso-leg, torso-foot, thigh-foot; hopper.xml:5)
+        q[k:2 * k, 3] = rng.uniform(-2.9, -0.9, k)
+        q[k:2 * k, 4] = rng.uniform(-2.9, -1.4, k)
+        q[k:2 * k, 5] = rng.uniform(-0.9, 0.9, k)
+        q[k:2 * k, 1] = rng.uniform(0.1, 2.5, k)
+        q[k:2 * k, 2] = rng.normal(0, 1.2, k)
     v = rng.normal(0, 2.0, (n, nv)) * np.where(np.arange(n) % 3 == 0, 5.0, 1.0)[:, None]
     s0 = np.concatenate([q, v], axis=1)
     act = rng.uniform(-1.3, 1.3, (n, nu)).astype(np.float32)
+    if body == "hopper":
+        pm = (O.planar_row_mask("hopper", s0[n // 4: n // 2][:400000]) >> 11) & 7
+        print(f"hopper: share of the folded quarter's states with a capsule-pair row {float((pm != 0).mean()):.3f} (torso-leg {float((pm & 1 != 0).mean()):.3f}, "
+              f"torso-foot {float((pm & 2 != 0).mean()):.3f}, thigh-foot {float((pm & 4 != 0).mean()):.3f})", flush=True)
     for integ, fr in (("euler", 1), ("rk4", 2)):
         eng = Engine(name, n, freq_rate=fr, real_time_scale=0.002, precision="ref", integrator=integ, solver="newton")
         eng.set_state(s0)
