@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     if constexpr (Body::kScratchPerLane > 0) trig.scratch = scratch_s;
     trig.scratch_stride = kBlock;
     trig.cap_hits = a.cap_hits;
+    EMEI_PROFILE_BEGIN();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t n = a.n;
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
                                           ((uint32_t)steps * (uint32_t)a.freq_rate + (uint32_t)k) * (uint32_t)((NS + 3) / 4),
                                           a.noise.obs, a.noise.shared != 0);
         }
+        EMEI_MARK(step_io);  // (the integrator's own arithmetic between two forward-dynamics evaluations is charged to nw_out)
         float o[NO];
         R rew;
         bool term;
@@ -359,6 +361,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
             if (a.reward_out) a.reward_out[(int64_t)t * n + i] = (float)rew;
             if (a.done_out) a.done_out[(int64_t)t * n + i] = (uint8_t)done;
         }
+        EMEI_MARK(step_reset);
         if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {
             if constexpr (Body::kSpareReset) {
                 // spare initial state per lane, re-drawn for every lane that lacks one when a resetting lane
@@ -391,6 +394,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     }
     unsigned long long mk = __ballot(done != 0);
     if (lane == 0 && active) a.done_mask[i / kWave] = mk;
+    EMEI_PROFILE_END();
 }
 
 template <class Body>

@@ -27,6 +27,17 @@ namespace emei {
 int EMEI_TU_NAME(const BodyLaunch& L) { return launch_body<EMEI_BODY_TYPE>(L); }
 }  // namespace emei
 
+#ifdef EMEI_CYCLE_PROFILE
+// variant builds only (tools/cycle_profile.py): copy out and clear this translation unit's per-region cycle sums
+#define EMEI_CATP2(a, b) a##b
+#define EMEI_CATP(a, b) EMEI_CATP2(a, b)
+extern "C" __attribute__((visibility("default"))) int EMEI_CATP(emei_cycle_stats_, EMEI_TU_NAME)(unsigned long long* out) {
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(emei::g_cycle_stats), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(emei::g_cycle_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #ifdef EMEI_NEWTON_STATS
 // variant builds only (tools/newton_stats.py): copy out and clear this translation unit's solver counters
 #define EMEI_CAT2(a, b) a##b

@@ -791,6 +791,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             // points a lane has is only known at run time.
             EMEI_STAT_LANE(22);
             EMEI_STAT_WAVE(23);
+            EMEI_MARK(dual_fill);
             R* const sl = (R*)trig.scratch + threadIdx.x;
             auto put = [&](int sidx, int fld, R val) __attribute__((always_inline)) { sl[(sidx * kSlotFields + fld) * trig.scratch_stride] = val; };
             auto get = [&](int sidx, int fld) __attribute__((always_inline)) { return sl[(sidx * kSlotFields + fld) * trig.scratch_stride]; };
@@ -882,6 +883,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 dcontact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
                 dcontact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
             }
+            EMEI_MARK(dual_gram);
             // slot data back (static slot index now); an absent second slot stays all zero: W_1 = 0, g_1 = 0
             R G00nn = R(0), G00nt = R(0), G00tt = R(0), G11nn = R(0), G11nt = R(0), G11tt = R(0);
             R G01nn = R(0), G01nt = R(0), G01tn = R(0), G01tt = R(0);
@@ -910,6 +912,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             // cold start (u = u0): g = 0 is the solution of the empty set, so if no edge is active there, a0 is the minimiser;
             // from a warm start the first pass always solves
             uint32_t used = warm.valid ? 0xffffffffu : 0u;
+            EMEI_MARK(dual_loop);
 #pragma unroll 1
             for (int it = 0; it < kMaxNewton; ++it) {
                 ++n_pass;
@@ -957,6 +960,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 un1 = u0n1 - (fma_r(G01nn, g0n, G01tn * g0t) + fma_r(G11nn, g1n, G11nt * g1t));
                 ut1 = u0t1 - (fma_r(G01nt, g0n, G01tt * g0t) + fma_r(G11nt, g1n, G11tt * g1t));
             }
+            EMEI_MARK(dual_final);
             // a = a0 - L^-T D^-1 sum_p Y_p g_p (Y read again from the slots: 36 values are not worth holding through the loop)
             R z[NV];
 #pragma unroll
@@ -1118,6 +1122,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
     }
+    EMEI_MARK(nw_euler);
     if (hd > R(0)) {
         // mj_EulerSkip for every lane: (M + h B) qacc = M a, as qacc = a - (M + h B)^-1 (h B a), for the lanes with rows;
         // free flight (a = 0 above): qacc = (M + h B)^-1 f = 0 - (M + h B)^-1 (-f)

@@ -36,12 +36,60 @@ static __device__ unsigned long long g_debug_stats[32];
 #define EMEI_STAT_WAVE(i) ((void)0)
 #endif
 
-// Region markers for tools/isa_regions.py (a comment line in the ISA; nothing in a normal build): the tool compiles a
-// translation unit with -DEMEI_ISA_MARKS and counts the vector instructions between consecutive marks.
-#ifdef EMEI_ISA_MARKS
+// Region markers.  Nothing in a normal build.  -DEMEI_ISA_MARKS (tools/isa_regions.py): a comment line in the ISA, for static
+// instruction counts per region.  -DEMEI_CYCLE_PROFILE (tools/cycle_profile.py, round 4): each mark charges the shader-clock
+// cycles since the wave's previous mark to the region that ENDS here — one atomic by the wave's first active lane, the running
+// (timestamp, region) pair in LDS (one-wave blocks: the body rollout kernels of the one-wave-per-SIMD bodies) — so that a run
+// reports where a wave's time goes, divergent regions and waits included.  COARSE by construction: a mark costs ~500 cycles of
+// its own (a scalar clock read and three dependent LDS operations by one lane) and hipcc moves pure arithmetic across it (the
+// factorisation that source code places behind `nw_smooth0` is hoisted in front of it), so only regions of several thousand
+// cycles mean anything.  Region ids: enum emei_region below.
+enum emei_region {
+    EMEI_R_entry = 0, EMEI_R_nw_trig, EMEI_R_nw_forces, EMEI_R_nw_rows, EMEI_R_nw_direct, EMEI_R_nw_smooth0, EMEI_R_dual_fill,
+    EMEI_R_dual_gram, EMEI_R_dual_loop, EMEI_R_dual_final, EMEI_R_nw_pass_base, EMEI_R_nw_limits, EMEI_R_nw_contacts, EMEI_R_nw_conv,
+    EMEI_R_nw_step, EMEI_R_nw_final, EMEI_R_nw_euler, EMEI_R_nw_out, EMEI_R_step_io, EMEI_R_step_reset, EMEI_R_count
+};
+#if defined(EMEI_ISA_MARKS)
 #define EMEI_MARK(name) asm volatile("; EMEI_MARK " #name)
+#elif defined(EMEI_CYCLE_PROFILE)
+static __device__ unsigned long long g_cycle_stats[32];
+struct CycleProfile {  // LDS of a one-wave block: per-region sums of this launch, the running (timestamp, region) pair
+    unsigned long long acc[32], last;
+    int prev;
+};
+__device__ __forceinline__ volatile CycleProfile* emei_cycle_lds() {
+    __shared__ CycleProfile p;
+    return &p;
+}
+__device__ __forceinline__ void emei_cycle_begin() {
+    volatile CycleProfile* p = emei_cycle_lds();
+    if (threadIdx.x < 32) p->acc[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) p->last = __builtin_readcyclecounter(), p->prev = EMEI_R_entry;
+    __syncthreads();
+}
+__device__ __forceinline__ void emei_cycle_mark(int region) {
+    volatile CycleProfile* p = emei_cycle_lds();
+    const unsigned long long now = __builtin_readcyclecounter();
+    if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {  // LDS only: ~100 cycles per mark
+        p->acc[p->prev] += now - p->last;
+        p->last = now, p->prev = region;
+    }
+}
+__device__ __forceinline__ void emei_cycle_end() {  // every thread of the block reaches this
+    volatile CycleProfile* p = emei_cycle_lds();
+    emei_cycle_mark(EMEI_R_entry);
+    __syncthreads();
+    if (threadIdx.x < EMEI_R_count) atomicAdd(&g_cycle_stats[threadIdx.x], p->acc[threadIdx.x]);
+}
+#define EMEI_MARK(name) emei::emei_cycle_mark(emei::EMEI_R_##name)
+#define EMEI_PROFILE_BEGIN() emei::emei_cycle_begin()
+#define EMEI_PROFILE_END() emei::emei_cycle_end()
 #else
 #define EMEI_MARK(name) ((void)0)
+#endif
+#ifndef EMEI_PROFILE_BEGIN
+#define EMEI_PROFILE_BEGIN() ((void)0)
+#define EMEI_PROFILE_END() ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
