@@ -228,6 +228,14 @@ __device__ __forceinline__ double fma_vsv(double a, double b_uniform, double c) 
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
     return d;
 }
+// a * b + c, all in vector registers, three-address (c survives): for an addend that is still needed afterwards
+__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_vvv(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float fma_vsv(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ void sincos_fast_ctx(const TrigCtx& t, double x, double& s, double& c) {
     fast_sincos_tab(x, t.tab, s, c);  // |x| <= kFastTrigLimitF64 (callers reduce first: sincos_ctx, sincos_begin_ctx)
 }
@@ -264,7 +272,9 @@ __device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, dou
     uint32_t addr;
     asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, 4, %2" : "=v"(addr) : "v"((uint32_t)__double2loint(shifted)), "s"(t.lds_base));
     asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
-    double r = __builtin_fma(-n, H1, x);
+    // x lives on (it is the state's angle): as fma(-n, H1, x) hipcc copies it first (v_mov_b64 + the two-address v_fmac_f64);
+    // the three-address form leaves it where it is
+    double r = fma_vsv(n, -H1, x);
     r = __builtin_fma(-n, H2, r);
     const double z = r * r;
     p.sr = __builtin_fma(r * z, fma_vsv(z, 1.0 / 120, t.c3), r);

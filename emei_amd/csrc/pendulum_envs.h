@@ -113,9 +113,12 @@ struct CartPole {
         R sn = c.sn, cs = c.cs;
         auto pending = sincos_begin_ctx(c.trig, s[2]);  // table read in flight under the dynamics
         sincos_pin(pending, sn, cs);
-        R temp = fma_r(A * (theta_dot * theta_dot), sn, force_over_m);
+        // three-address FMAs where the addend outlives the product (force / M: its low half is shared by both actions; L43: a
+        // constant): hipcc's two-address v_fmac_f64 copies the addend first (3 v_mov_b64 of a step's 75 vector instructions,
+        // with the angle reduction of emei_device.h:sincos_begin_ctx)
+        R temp = fma_vvv(A * (theta_dot * theta_dot), sn, force_over_m);
         R num = fma_r(gravity, sn, -(cs * temp));
-        R den = fma_r(-B, cs * cs, L43);
+        R den = fma_vsv(cs * cs, -B, L43);
         R theta_acc = div_r(num, den);
         R x_acc = fma_r(-(A * theta_acc), cs, temp);
         // derivative rounded to float32 (cartpole.py:60), float32 product with float32(dt)
