@@ -545,6 +545,7 @@ struct NewtonWarm {
 template <typename R>
 __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV], const R (&ctrl)[3], const Model& m, R hd,
                                              R (&qacc)[NV], const TrigCtx& trig, NewtonWarm<R>& warm) {
+    EMEI_MARK(nw_trig);
     R phi[NL], om[NL];
     phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
     phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
@@ -608,6 +609,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     org[L_THIGH] = V2<R>{org[L_TORSO].x + D[L_TORSO].x, org[L_TORSO].z + D[L_TORSO].z};
     org[L_LEG] = V2<R>{org[L_THIGH].x + D[L_THIGH].x, org[L_THIGH].z + D[L_THIGH].z};
     org[L_FOOT] = V2<R>{org[L_LEG].x + D[L_LEG].x, org[L_LEG].z + D[L_LEG].z};
+    EMEI_MARK(nw_rows);
     // rows that exist (geometry only): bits 0-2 joint limits, 3-10 contact points, 11-13 capsule pairs
     uint32_t rows = 0;
 #pragma unroll
@@ -628,6 +630,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     R A[NV][NV], invd[NV], a[NV];
     EMEI_STAT_LANE(0);
     EMEI_STAT_WAVE(7);
+    EMEI_MARK(nw_smooth0);
     // qacc_smooth = M^-1 qfrc_smooth for every lane (cheetah_model.h): free flight without implicit damping, the cold start
     build_inertia(A, R(0));
     ldl_factor(A, invd);
@@ -672,10 +675,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             ++n_pass;
             EMEI_STAT_LANE(2);
             EMEI_STAT_WAVE(3);
+            EMEI_MARK(nw_pass_base);
             build_inertia(A, R(0));
             sym_matvec(A, a, gr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gr[i] -= f[i];
+            EMEI_MARK(nw_limits);
             uint32_t flags = 0;  // the active set this pass assembles: bit k = limit row k, bits 3 + 3 pt .. = the point's edges (s1, s2, sy), bit 27 + pair
             auto limit = [&](auto kc) __attribute__((always_inline)) {  // theta_k = phi_P - phi_C: J = +-(e_P - e_C)
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
@@ -700,6 +705,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 }
             };
             limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
+            EMEI_MARK(nw_contacts);
             auto contact = [&](auto pt_c) __attribute__((always_inline)) {
                 constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
                 if (rows & (1u << (3 + pt))) {
@@ -758,6 +764,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact(integral_constant<int, 0>{}), contact(integral_constant<int, 1>{}), contact(integral_constant<int, 2>{});
             contact(integral_constant<int, 3>{}), contact(integral_constant<int, 4>{}), contact(integral_constant<int, 5>{});
             contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
+            EMEI_MARK(hp_pairs);
             auto pair = [&](auto pc) __attribute__((always_inline)) {
                 constexpr int P = decltype(pc)::value, G1 = kPairGeom[P][0], G2 = kPairGeom[P][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
                 if (rows & (1u << (11 + P))) {
@@ -788,6 +795,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 }
             };
             pair(integral_constant<int, 0>{}), pair(integral_constant<int, 1>{}), pair(integral_constant<int, 2>{});
+            EMEI_MARK(nw_conv);
             R gmax = R(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) gmax = gmax > fabs(gr[i]) ? gmax : fabs(gr[i]);
@@ -795,6 +803,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 converged = true;
                 break;
             }
+            EMEI_MARK(nw_step);
             ldl_factor(A, invd);
             ldl_forward<0>(A, gr);
 #pragma unroll
@@ -810,6 +819,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             // RK4 steps (86 % of the warm-started lanes take one step and then only verify); in the Euler kernel, where every
             // evaluation starts cold, the sweep costs what it saves (8.035 -> 8.08 ms).
             if (!warm.stages) continue;
+            EMEI_MARK(hp_verify);
             uint32_t again = 0;
             auto limit2 = [&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
@@ -872,12 +882,14 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 break;
             }
         }
+        EMEI_MARK(nw_final);
         EMEI_STAT_LANE(8 + (n_pass < 13 ? n_pass : 13));
         report_cap_hit(trig, !converged);
 #pragma unroll
         for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
         warm.valid = true;
     }
+    EMEI_MARK(nw_euler);
     if (hd > R(0)) {  // mj_EulerSkip for every lane: qacc = a - (M + h B)^-1 (h B a); free flight (a = 0): rhs = -f
         R rhs[NV];
 #pragma unroll
@@ -896,6 +908,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] -= rhs[i];
     }
+    EMEI_MARK(nw_out);
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[L_TORSO];
     qacc[3] = a[L_TORSO] - a[L_THIGH], qacc[4] = a[L_THIGH] - a[L_LEG], qacc[5] = a[L_LEG] - a[L_FOOT];
 }

@@ -22,7 +22,8 @@ from emei_amd import _lib  # noqa: E402
 from emei_amd.sharding import ShardedRollout  # noqa: E402
 
 REGIONS = ["entry", "nw_trig", "nw_forces", "nw_rows", "nw_direct", "nw_smooth0", "dual_fill", "dual_gram", "dual_loop", "dual_final",
-           "nw_pass_base", "nw_limits", "nw_contacts", "nw_conv", "nw_step", "nw_final", "nw_euler", "nw_out", "step_io", "step_reset"]
+           "nw_pass_base", "nw_limits", "nw_contacts", "nw_conv", "nw_step", "nw_final", "nw_euler", "nw_out", "step_io", "step_reset",
+           "hp_pairs", "hp_verify"]
 WHAT = {"entry": "(kernel prologue / between steps)", "nw_trig": "7 sincos, rotated link vectors", "nw_forces": "smooth forces",
         "nw_rows": "which rows exist (16 points, 6 limits)", "nw_direct": "free-flight solve", "nw_smooth0": "M = L D L', qacc_smooth",
         "dual_fill": "constraint slots: J, L^-1 J', LDS puts (union of the wave's blocks)", "dual_gram": "slots back, G = Y' D^-1 Y",
@@ -30,7 +31,8 @@ WHAT = {"entry": "(kernel prologue / between steps)", "nw_trig": "7 sincos, rota
         "nw_pass_base": "primal loop: gradient base", "nw_limits": "primal loop: limit rows", "nw_contacts": "primal loop: contact rows",
         "nw_conv": "primal loop: convergence test", "nw_step": "primal loop: factor H, Newton step", "nw_final": "warm store / cap report",
         "nw_euler": "Euler damping step: factor M + h B, solve", "nw_out": "back to joint coordinates + the integrator's update",
-        "step_io": "outputs: reward / terminal / obs staging and stores", "step_reset": "auto-reset check (+ action staging of the next step)"}
+        "step_io": "outputs: reward / terminal / obs staging and stores", "step_reset": "auto-reset check (+ action staging of the next step)", "hp_pairs": "primal loop: capsule-pair rows (Hopper)",
+        "hp_verify": "primal loop: re-evaluation of the rows' residuals after the step (RK4 kernels)"}
 env, integ, tu = (sys.argv[1:4] + ["HalfCheetahRunning", "euler", "body_tu_ch_f64"][len(sys.argv) - 1:])[:3]
 
 
