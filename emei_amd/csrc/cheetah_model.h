@@ -730,6 +730,23 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         rows |= (org_of[L].z + ez - (R)kGeom.radius < R(0)) ? (1u << (6 + pt)) : 0u;
     }
 
+    // A lane with THREE row blocks borrows, for its third block, the second slot of a lane of its wave that leaves it unused (a
+    // lane with at most one block, or none: 74 % of the lanes): same LDS, same layout, another column.  Wave-uniform scalar loop
+    // over the few such lanes (3 per 1000); a lane without a donor keeps the primal loop.  (Round 4: the primal loop ran for 0.3 %
+    // of the lanes but in 15.6 % of the wave evaluations, and cost 27 % of config 4: 7.75 -> 5.65 ms with the loop cut out.)
+    int donor = -1;
+    if (kDualSlots > 0 && trig.scratch != nullptr) {
+        const int nb = __popc(rows);
+        unsigned long long tri_m = __ballot(nb == 3);
+        if (__builtin_expect(tri_m != 0ull, 0)) {  // 16 % of the wave evaluations; one or two iterations
+            unsigned long long don_m = __ballot(nb <= 1);
+            const int ln = (int)(threadIdx.x & (kWave - 1));
+            while (tri_m != 0ull && don_m != 0ull) {
+                if (ln == __ffsll(tri_m) - 1) donor = __ffsll(don_m) - 1;
+                tri_m &= tri_m - 1ull, don_m &= don_m - 1ull;
+            }
+        }
+    }
     EMEI_MARK(nw_direct);
     EMEI_STAT_LANE(0);
     EMEI_STAT_WAVE(7);
@@ -756,7 +773,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
         EMEI_STAT_LANE(25 + (__popc(rows) < 6 ? __popc(rows) : 6));  // 26..31: lanes with 1, 2, 3, 4, 5, >= 6 row blocks
         // the start of the iteration: the previous minimiser, else qacc_smooth = M^-1 qfrc_smooth (the dual path always
         // needs M's factor and qacc_smooth; a previous minimiser then only provides its first active set)
-        const bool dual = kDualSlots > 0 && trig.scratch != nullptr && __popc(rows) <= kDualSlots;
+        const bool dual = kDualSlots > 0 && trig.scratch != nullptr && (__popc(rows) <= kDualSlots || donor >= 0);
         if (warm.valid && !dual) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = warm.a[i];
@@ -793,8 +810,15 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             EMEI_STAT_WAVE(23);
             EMEI_MARK(dual_fill);
             R* const sl = (R*)trig.scratch + threadIdx.x;
-            auto put = [&](int sidx, int fld, R val) __attribute__((always_inline)) { sl[(sidx * kSlotFields + fld) * trig.scratch_stride] = val; };
+            // slot 2 = slot 1 of the donor's column (this lane writes and reads it itself; the donor never touches its slot 1)
+            R* const sl1 = sl + kSlotFields * trig.scratch_stride;
+            R* const sl2 = (R*)trig.scratch + ((int)(threadIdx.x & ~(kWave - 1)) + (donor >= 0 ? donor : (int)(threadIdx.x & (kWave - 1)))) +
+                           kSlotFields * trig.scratch_stride;
+            // the block's slot: chosen ONCE per block (as a select inside every store it cost 5 800 cycles per evaluation)
+            auto slot_base = [&](int sidx) __attribute__((always_inline)) { return sidx == 0 ? sl : (sidx == 1 ? sl1 : sl2); };
+            auto put = [&](R* sp, int fld, R val) __attribute__((always_inline)) { sp[fld * trig.scratch_stride] = val; };
             auto get = [&](int sidx, int fld) __attribute__((always_inline)) { return sl[(sidx * kSlotFields + fld) * trig.scratch_stride]; };
+            auto get2 = [&](int fld) __attribute__((always_inline)) { return sl2[fld * trig.scratch_stride]; };
             const R mu = (R)kGeom.friction;
             int slot = 0;
             // a violated joint limit is a slot with one direction: J = +-(e_C - e_P), no tangent, mu = 0 and D / 4 (with
@@ -802,6 +826,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             auto dlimit = [&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value, C = jc[k], P = jp[k];
                 if (rows & (1u << k)) {
+                    R* const sp = slot_base(slot);
                     const R th = q[3 + k];
                     const bool lower = th < (R)kGeom.lo[k];
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
@@ -814,10 +839,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R an = J * (a[C] - a[P]), wn = J * (warm.a[C] - warm.a[P]);
                     ldl_forward<C, false>(A, Jn);
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) put(slot, i, in_pat(C, i) ? Jn[i] : R(0)), put(slot, NV + i, R(0));
-                    put(slot, 18, an), put(slot, 19, R(0)), put(slot, 20, -aref), put(slot, 21, R(0));
-                    put(slot, 22, R(0.25) * div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]));
-                    put(slot, 23, warm.valid ? wn : an), put(slot, 24, R(0)), put(slot, 25, R(0));
+                    for (int i = 0; i < NV; ++i) put(sp, i, in_pat(C, i) ? Jn[i] : R(0)), put(sp, NV + i, R(0));
+                    put(sp, 18, an), put(sp, 19, R(0)), put(sp, 20, -aref), put(sp, 21, R(0));
+                    put(sp, 22, R(0.25) * div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]));
+                    put(sp, 23, warm.valid ? wn : an), put(sp, 24, R(0)), put(sp, 25, R(0));
                     ++slot;
                 }
             };
@@ -827,6 +852,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                                 __attribute__((always_inline)) {
                 constexpr int LNK = decltype(lnk_c)::value;
                 if (rows & (1u << (6 + pt))) {
+                    R* const sp = slot_base(slot);
                     const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
                     const R dist = org.z + e.z - (R)kGeom.radius;
                     const V2<R> r = {e.x, R(0.5) * dist - org.z};
@@ -853,12 +879,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     ldl_forward<LNK, false>(A, Jx);
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
-                        put(slot, i, in_pat(LNK, i) ? Jz[i] : R(0));
-                        put(slot, NV + i, in_pat(LNK, i) ? Jx[i] : R(0));
+                        put(sp, i, in_pat(LNK, i) ? Jz[i] : R(0));
+                        put(sp, NV + i, in_pat(LNK, i) ? Jx[i] : R(0));
                     }
-                    put(slot, 18, an), put(slot, 19, at);
-                    put(slot, 20, (R)m.cB * vn + (R)m.cK * imp * dist), put(slot, 21, (R)m.cB * vt), put(slot, 22, Dw);
-                    put(slot, 23, warm.valid ? wn : an), put(slot, 24, warm.valid ? wt : at), put(slot, 25, mu);
+                    put(sp, 18, an), put(sp, 19, at);
+                    put(sp, 20, (R)m.cB * vn + (R)m.cK * imp * dist), put(sp, 21, (R)m.cB * vt), put(sp, 22, Dw);
+                    put(sp, 23, warm.valid ? wn : an), put(sp, 24, warm.valid ? wt : at), put(sp, 25, mu);
                     ++slot;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -883,6 +909,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                 dcontact(14, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
                 dcontact(15, integral_constant<int, P_FFOOT>{}, o_ff, P_TORSO, Dtf, P_FTHIGH, Dft, P_FSHIN, Dfs);
             }
+            if (slot <= 2) {
             EMEI_MARK(dual_gram);
             // slot data back (static slot index now); an absent second slot stays all zero: W_1 = 0, g_1 = 0
             R G00nn = R(0), G00nt = R(0), G00tt = R(0), G11nn = R(0), G11nt = R(0), G11tt = R(0);
@@ -974,6 +1001,149 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             ldl_backward(A, z);
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] -= z[i];
+            } else {
+                // ---- three row blocks: the same linear system (I + W G) g = W (u0 + b), now 6 x 6.  Block 0 is eliminated first,
+                //   g0 = y0 - E01 g1 - E02 g2,  y0 = P0^-1 W0 s0,  E0j = P0^-1 W0 G0j,  P0 = I + W0 G00   (det P0 >= 1)
+                // which leaves a system of the SAME form for blocks 1, 2 with the Schur complements G'ij = Gij - Gi0 E0j (symmetric:
+                // P0^-1 W0 is) and right-hand sides W_i (s_i - Gi0 y0): solved by the two-block elimination above.
+                EMEI_MARK(tri_gram);
+                struct S2 { R nn, nt, tt; };      // symmetric 2 x 2
+                struct G2 { R nn, nt, tn, tt; };  // general 2 x 2: rows = components (n, t) of the first block
+                S2 Ga = {R(0), R(0), R(0)}, Gb = Ga, Gc = Ga;                     // G00, G11, G22
+                G2 Gab = {R(0), R(0), R(0), R(0)}, Gac = Gab, Gbc = Gab;            // G01, G02, G12
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {  // one row of the three Y pairs at a time: 21 accumulators, 6 values in flight
+                    const R an = get(0, i), at = get(0, NV + i), bn = get(1, i), bt = get(1, NV + i), cn = get2(i), ct = get2(NV + i);
+                    const R dan = invd[i] * an, dat = invd[i] * at, dbn = invd[i] * bn, dbt = invd[i] * bt, dcn = invd[i] * cn, dct = invd[i] * ct;
+                    Ga.nn = fma_r(dan, an, Ga.nn), Ga.nt = fma_r(dan, at, Ga.nt), Ga.tt = fma_r(dat, at, Ga.tt);
+                    Gb.nn = fma_r(dbn, bn, Gb.nn), Gb.nt = fma_r(dbn, bt, Gb.nt), Gb.tt = fma_r(dbt, bt, Gb.tt);
+                    Gc.nn = fma_r(dcn, cn, Gc.nn), Gc.nt = fma_r(dcn, ct, Gc.nt), Gc.tt = fma_r(dct, ct, Gc.tt);
+                    Gab.nn = fma_r(dan, bn, Gab.nn), Gab.nt = fma_r(dan, bt, Gab.nt), Gab.tn = fma_r(dat, bn, Gab.tn), Gab.tt = fma_r(dat, bt, Gab.tt);
+                    Gac.nn = fma_r(dan, cn, Gac.nn), Gac.nt = fma_r(dan, ct, Gac.nt), Gac.tn = fma_r(dat, cn, Gac.tn), Gac.tt = fma_r(dat, ct, Gac.tt);
+                    Gbc.nn = fma_r(dbn, cn, Gbc.nn), Gbc.nt = fma_r(dbn, ct, Gbc.nt), Gbc.tn = fma_r(dbt, cn, Gbc.tn), Gbc.tt = fma_r(dbt, ct, Gbc.tt);
+                    // hipcc would hoist all 54 slot reads of the unrolled loop in front of it (108 registers the kernel does not
+                    // have: scratch); a scheduling barrier per two rows keeps 12 in flight
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                // per block: the current u (n, t) in registers; u0, b, weight, friction stay in the slots and are read per pass (18
+                // values that would otherwise be live across the whole loop: the kernel is at the register file's limit)
+                auto fld = [&](int k, int f) __attribute__((always_inline)) { return k < 2 ? get(k, f) : get2(f); };
+                R un[3], ut[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) un[k] = fld(k, 23), ut[k] = fld(k, 24);
+                R gn[3] = {R(0), R(0), R(0)}, gt[3] = {R(0), R(0), R(0)};
+                uint32_t used = warm.valid ? 0xffffffffu : 0u;
+                EMEI_MARK(tri_loop);
+#pragma unroll 1
+                for (int it = 0; it < kMaxNewton; ++it) {
+                    ++n_pass;
+                    EMEI_STAT_LANE(2);
+                    EMEI_STAT_WAVE(3);
+                    uint32_t flags = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {  // active pyramid edges of block k at the current iterate
+                        const R bn_k = fld(k, 20), bt_k = fld(k, 21), mu_k = fld(k, 25);
+                        const R xn = un[k] + bn_k, xt = mu_k * (ut[k] + bt_k);
+                        flags |= ((xn + xt < R(0) ? 1u : 0u) | (xn - xt < R(0) ? 2u : 0u) | (xn < R(0) ? 4u : 0u)) << (3 * k);
+                    }
+                    if (flags == used) {
+                        converged = true;
+                        break;
+                    }
+                    used = flags;
+                    // weight matrix W_k of block k's active edges and r_k = W_k (u0_k + b_k): formed where they are consumed (every
+                    // value kept live across the elimination is one the register file does not have)
+                    auto weights = [&](int k, S2& W, R& rn, R& rt) __attribute__((always_inline)) {
+                        const R Dw_k = fld(k, 22), mu_k = fld(k, 25);
+                        const uint32_t fk = flags >> (3 * k);
+                        const R c1 = (fk & 1u) ? R(1) : R(0), c2 = (fk & 2u) ? R(1) : R(0), cy = (fk & 4u) ? R(2) : R(0);
+                        W.nn = Dw_k * (c1 + c2 + cy), W.nt = Dw_k * mu_k * (c1 - c2), W.tt = Dw_k * mu_k * mu_k * (c1 + c2);
+                        const R sn_ = fld(k, 18) + fld(k, 20), st_ = fld(k, 19) + fld(k, 21);
+                        rn = fma_r(W.nn, sn_, W.nt * st_), rt = fma_r(W.nt, sn_, W.tt * st_);
+                    };
+                    // block 0 out: P0 = I + W0 G00, T = P0^-1 W0, y0 = P0^-1 r0
+                    R y0n, y0t;
+                    G2 Eb, Ec;
+                    {
+                        S2 W0;
+                        R r0n, r0t;
+                        weights(0, W0, r0n, r0t);
+                        const R p00 = R(1) + fma_r(W0.nn, Ga.nn, W0.nt * Ga.nt), p01 = fma_r(W0.nn, Ga.nt, W0.nt * Ga.tt);
+                        const R p10 = fma_r(W0.nt, Ga.nn, W0.tt * Ga.nt), p11 = R(1) + fma_r(W0.nt, Ga.nt, W0.tt * Ga.tt);
+                        const R id0 = rcp_r(fma_r(p00, p11, -(p01 * p10)));
+                        const R t00 = fma_r(p11, W0.nn, -(p01 * W0.nt)) * id0, t01 = fma_r(p11, W0.nt, -(p01 * W0.tt)) * id0;
+                        const R t10 = fma_r(p00, W0.nt, -(p10 * W0.nn)) * id0, t11 = fma_r(p00, W0.tt, -(p10 * W0.nt)) * id0;
+                        y0n = fma_r(p11, r0n, -(p01 * r0t)) * id0, y0t = fma_r(p00, r0t, -(p10 * r0n)) * id0;
+                        // E0j = T G0j (j = b, c)
+                        Eb = G2{fma_r(t00, Gab.nn, t01 * Gab.tn), fma_r(t00, Gab.nt, t01 * Gab.tt), fma_r(t10, Gab.nn, t11 * Gab.tn), fma_r(t10, Gab.nt, t11 * Gab.tt)};
+                        Ec = G2{fma_r(t00, Gac.nn, t01 * Gac.tn), fma_r(t00, Gac.nt, t01 * Gac.tt), fma_r(t10, Gac.nn, t11 * Gac.tn), fma_r(t10, Gac.nt, t11 * Gac.tt)};
+                    }
+                    // Schur complements: G'bb = Gbb - Gba Eb, G'cc = Gcc - Gca Ec, G'bc = Gbc - Gba Ec   (Gba = Gab')
+                    const S2 Hb = {Gb.nn - fma_r(Gab.nn, Eb.nn, Gab.tn * Eb.tn), Gb.nt - fma_r(Gab.nn, Eb.nt, Gab.tn * Eb.tt),
+                                   Gb.tt - fma_r(Gab.nt, Eb.nt, Gab.tt * Eb.tt)};
+                    const S2 Hc = {Gc.nn - fma_r(Gac.nn, Ec.nn, Gac.tn * Ec.tn), Gc.nt - fma_r(Gac.nn, Ec.nt, Gac.tn * Ec.tt),
+                                   Gc.tt - fma_r(Gac.nt, Ec.nt, Gac.tt * Ec.tt)};
+                    const G2 Hbc = {Gbc.nn - fma_r(Gab.nn, Ec.nn, Gab.tn * Ec.tn), Gbc.nt - fma_r(Gab.nn, Ec.nt, Gab.tn * Ec.tt),
+                                    Gbc.tn - fma_r(Gab.nt, Ec.nn, Gab.tt * Ec.tn), Gbc.tt - fma_r(Gab.nt, Ec.nt, Gab.tt * Ec.tt)};
+                    // Gi0 y0 for the right-hand sides r'_i = r_i - W_i (Gi0 y0)
+                    const R db_n = fma_r(Gab.nn, y0n, Gab.tn * y0t), db_t = fma_r(Gab.nt, y0n, Gab.tt * y0t);
+                    const R dc_n = fma_r(Gac.nn, y0n, Gac.tn * y0t), dc_t = fma_r(Gac.nt, y0n, Gac.tt * y0t);
+                    // the two-block elimination on (Hb, Hc, Hbc), as in the two-slot path: block b out, then block c
+                    R ybn, ybt;
+                    G2 F;
+                    {
+                        S2 W1;
+                        R r1n, r1t;
+                        weights(1, W1, r1n, r1t);
+                        const R rbn = r1n - fma_r(W1.nn, db_n, W1.nt * db_t), rbt = r1t - fma_r(W1.nt, db_n, W1.tt * db_t);
+                        const R q00 = R(1) + fma_r(W1.nn, Hb.nn, W1.nt * Hb.nt), q01 = fma_r(W1.nn, Hb.nt, W1.nt * Hb.tt);
+                        const R q10 = fma_r(W1.nt, Hb.nn, W1.tt * Hb.nt), q11 = R(1) + fma_r(W1.nt, Hb.nt, W1.tt * Hb.tt);
+                        const R id1 = rcp_r(fma_r(q00, q11, -(q01 * q10)));
+                        const R v00 = fma_r(q11, W1.nn, -(q01 * W1.nt)) * id1, v01 = fma_r(q11, W1.nt, -(q01 * W1.tt)) * id1;
+                        const R v10 = fma_r(q00, W1.nt, -(q10 * W1.nn)) * id1, v11 = fma_r(q00, W1.tt, -(q10 * W1.nt)) * id1;
+                        ybn = fma_r(q11, rbn, -(q01 * rbt)) * id1, ybt = fma_r(q00, rbt, -(q10 * rbn)) * id1;
+                        F = G2{fma_r(v00, Hbc.nn, v01 * Hbc.tn), fma_r(v00, Hbc.nt, v01 * Hbc.tt), fma_r(v10, Hbc.nn, v11 * Hbc.tn), fma_r(v10, Hbc.nt, v11 * Hbc.tt)};
+                    }
+                    {
+                        S2 W2;
+                        R r2n, r2t;
+                        weights(2, W2, r2n, r2t);
+                        const R rcn = r2n - fma_r(W2.nn, dc_n, W2.nt * dc_t), rct = r2t - fma_r(W2.nt, dc_n, W2.tt * dc_t);
+                        const R k00 = Hc.nn - fma_r(Hbc.nn, F.nn, Hbc.tn * F.tn), k01 = Hc.nt - fma_r(Hbc.nn, F.nt, Hbc.tn * F.tt);
+                        const R k10 = Hc.nt - fma_r(Hbc.nt, F.nn, Hbc.tt * F.tn), k11 = Hc.tt - fma_r(Hbc.nt, F.nt, Hbc.tt * F.tt);
+                        const R m00 = R(1) + fma_r(W2.nn, k00, W2.nt * k10), m01 = fma_r(W2.nn, k01, W2.nt * k11);
+                        const R m10 = fma_r(W2.nt, k00, W2.tt * k10), m11 = R(1) + fma_r(W2.nt, k01, W2.tt * k11);
+                        const R e0 = fma_r(Hbc.nn, ybn, Hbc.tn * ybt), e1 = fma_r(Hbc.nt, ybn, Hbc.tt * ybt);
+                        const R kcn = rcn - fma_r(W2.nn, e0, W2.nt * e1), kct = rct - fma_r(W2.nt, e0, W2.tt * e1);
+                        const R id2 = rcp_r(fma_r(m00, m11, -(m01 * m10)));
+                        gn[2] = fma_r(m11, kcn, -(m01 * kct)) * id2, gt[2] = fma_r(m00, kct, -(m10 * kcn)) * id2;
+                    }
+                    gn[1] = ybn - fma_r(F.nn, gn[2], F.nt * gt[2]), gt[1] = ybt - fma_r(F.tn, gn[2], F.tt * gt[2]);
+                    gn[0] = y0n - (fma_r(Eb.nn, gn[1], Eb.nt * gt[1]) + fma_r(Ec.nn, gn[2], Ec.nt * gt[2]));
+                    gt[0] = y0t - (fma_r(Eb.tn, gn[1], Eb.tt * gt[1]) + fma_r(Ec.tn, gn[2], Ec.tt * gt[2]));
+                    // u = u0 - G g
+                    un[0] = fld(0, 18) - (fma_r(Ga.nn, gn[0], Ga.nt * gt[0]) + fma_r(Gab.nn, gn[1], Gab.nt * gt[1]) + fma_r(Gac.nn, gn[2], Gac.nt * gt[2]));
+                    ut[0] = fld(0, 19) - (fma_r(Ga.nt, gn[0], Ga.tt * gt[0]) + fma_r(Gab.tn, gn[1], Gab.tt * gt[1]) + fma_r(Gac.tn, gn[2], Gac.tt * gt[2]));
+                    un[1] = fld(1, 18) - (fma_r(Gab.nn, gn[0], Gab.tn * gt[0]) + fma_r(Gb.nn, gn[1], Gb.nt * gt[1]) + fma_r(Gbc.nn, gn[2], Gbc.nt * gt[2]));
+                    ut[1] = fld(1, 19) - (fma_r(Gab.nt, gn[0], Gab.tt * gt[0]) + fma_r(Gb.nt, gn[1], Gb.tt * gt[1]) + fma_r(Gbc.tn, gn[2], Gbc.tt * gt[2]));
+                    un[2] = fld(2, 18) - (fma_r(Gac.nn, gn[0], Gac.tn * gt[0]) + fma_r(Gbc.nn, gn[1], Gbc.tn * gt[1]) + fma_r(Gc.nn, gn[2], Gc.nt * gt[2]));
+                    ut[2] = fld(2, 19) - (fma_r(Gac.nt, gn[0], Gac.tt * gt[0]) + fma_r(Gbc.nt, gn[1], Gbc.tt * gt[1]) + fma_r(Gc.nt, gn[2], Gc.tt * gt[2]));
+                }
+                EMEI_MARK(tri_final);
+                // a = a0 - L^-T D^-1 sum_p Y_p g_p
+                R z[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    z[i] = fma_r(get(0, i), gn[0], get(0, NV + i) * gt[0]) + fma_r(get(1, i), gn[1], get(1, NV + i) * gt[1]) +
+                           fma_r(get2(i), gn[2], get2(NV + i) * gt[2]);
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) z[i] *= invd[i];
+                ldl_backward(A, z);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) a[i] -= z[i];
+            }
         } else {
         EMEI_STAT_LANE(24);
         EMEI_STAT_WAVE(25);

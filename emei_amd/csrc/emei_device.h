@@ -47,7 +47,7 @@ static __device__ unsigned long long g_debug_stats[32];
 enum emei_region {
     EMEI_R_entry = 0, EMEI_R_nw_trig, EMEI_R_nw_forces, EMEI_R_nw_rows, EMEI_R_nw_direct, EMEI_R_nw_smooth0, EMEI_R_dual_fill,
     EMEI_R_dual_gram, EMEI_R_dual_loop, EMEI_R_dual_final, EMEI_R_nw_pass_base, EMEI_R_nw_limits, EMEI_R_nw_contacts, EMEI_R_nw_conv,
-    EMEI_R_nw_step, EMEI_R_nw_final, EMEI_R_nw_euler, EMEI_R_nw_out, EMEI_R_step_io, EMEI_R_step_reset, EMEI_R_hp_pairs, EMEI_R_hp_verify, EMEI_R_count
+    EMEI_R_nw_step, EMEI_R_nw_final, EMEI_R_nw_euler, EMEI_R_nw_out, EMEI_R_step_io, EMEI_R_step_reset, EMEI_R_hp_pairs, EMEI_R_hp_verify, EMEI_R_tri_gram, EMEI_R_tri_loop, EMEI_R_tri_final, EMEI_R_count
 };
 #if defined(EMEI_ISA_MARKS)
 #define EMEI_MARK(name) asm volatile("; EMEI_MARK " #name)

@@ -51,6 +51,34 @@ def test_onestep_vs_oracle(fr, dt, precision, solver):
     assert np.array_equal((done.cpu().numpy() & 1).astype(bool), o_term) and not o_term.any()
 
 
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_lanes_with_three_row_blocks_vs_oracle(integrator):
+    """Round 4: a lane with exactly three row blocks (contact points / violated limits) iterates in constraint space too, its
+    third block in the unused second slot of a wave-mate (cheetah_model.h: `donor`); four and more keep the primal loop.  States
+    are drawn until the oracle's row mask says a few hundred lanes have exactly 3 blocks, 4+ blocks, 2 and fewer — mixed inside
+    the same waves, so that donors are taken and some three-block lanes find none; all against the oracle to 1e-9."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(31)
+    pool = _states(rng, 60000)
+    pool[:, 1] = rng.uniform(-0.45, 0.1, len(pool))  # lower: more points on the floor
+    nb = np.array([bin(int(m)).count("1") for m in O.planar_row_mask("cheetah", pool)])
+    pick = np.concatenate([np.nonzero(nb == 3)[0][:700], np.nonzero(nb >= 4)[0][:200], np.nonzero(nb <= 2)[0][:636]])
+    assert (nb[pick] == 3).sum() >= 300 and (nb[pick] >= 4).sum() >= 50
+    pick = rng.permutation(pick)
+    s0 = pool[pick]
+    # one wave made of three-block lanes only: no donor there (the primal fallback), another with a single donor
+    s0[:64] = pool[np.nonzero(nb == 3)[0][:64]]
+    s0[64:127] = pool[np.nonzero(nb == 3)[0][64:127]]
+    act = rng.uniform(-1.2, 1.2, (len(s0), 6)).astype(np.float32)
+    eng = _engine("HalfCheetahRunning", len(s0), freq_rate=2, real_time_scale=0.002, integrator=integrator)
+    eng.set_state(s0)
+    eng.step(torch.as_tensor(act, device=eng.device))
+    want, _, _ = O.cheetah_step(s0, act.astype(np.float64), 2, 0.002, O.opts(integrator))
+    assert rel_err(eng.get_state().cpu().numpy(), want, floor=1.0) <= 1e-9
+    assert eng.solver_cap_hits() == 0
+
+
 def test_rollout_segments_vs_oracle_and_step_equivalence():
     from oracle import oracle as O
 

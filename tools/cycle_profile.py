@@ -23,7 +23,7 @@ from emei_amd.sharding import ShardedRollout  # noqa: E402
 
 REGIONS = ["entry", "nw_trig", "nw_forces", "nw_rows", "nw_direct", "nw_smooth0", "dual_fill", "dual_gram", "dual_loop", "dual_final",
            "nw_pass_base", "nw_limits", "nw_contacts", "nw_conv", "nw_step", "nw_final", "nw_euler", "nw_out", "step_io", "step_reset",
-           "hp_pairs", "hp_verify"]
+           "hp_pairs", "hp_verify", "tri_gram", "tri_loop", "tri_final"]
 WHAT = {"entry": "(kernel prologue / between steps)", "nw_trig": "7 sincos, rotated link vectors", "nw_forces": "smooth forces",
         "nw_rows": "which rows exist (16 points, 6 limits)", "nw_direct": "free-flight solve", "nw_smooth0": "M = L D L', qacc_smooth",
         "dual_fill": "constraint slots: J, L^-1 J', LDS puts (union of the wave's blocks)", "dual_gram": "slots back, G = Y' D^-1 Y",
@@ -32,7 +32,9 @@ WHAT = {"entry": "(kernel prologue / between steps)", "nw_trig": "7 sincos, rota
         "nw_conv": "primal loop: convergence test", "nw_step": "primal loop: factor H, Newton step", "nw_final": "warm store / cap report",
         "nw_euler": "Euler damping step: factor M + h B, solve", "nw_out": "back to joint coordinates + the integrator's update",
         "step_io": "outputs: reward / terminal / obs staging and stores", "step_reset": "auto-reset check (+ action staging of the next step)", "hp_pairs": "primal loop: capsule-pair rows (Hopper)",
-        "hp_verify": "primal loop: re-evaluation of the rows' residuals after the step (RK4 kernels)"}
+        "hp_verify": "primal loop: re-evaluation of the rows' residuals after the step (RK4 kernels)",
+        "tri_gram": "three-block lanes: G (6 x 6) from three slots", "tri_loop": "three-block lanes: active-set passes",
+        "tri_final": "three-block lanes: a = a0 - L^-T D^-1 sum Y g"}
 env, integ, tu = (sys.argv[1:4] + ["HalfCheetahRunning", "euler", "body_tu_ch_f64"][len(sys.argv) - 1:])[:3]
 
 
