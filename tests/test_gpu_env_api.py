@@ -184,3 +184,28 @@ def test_freeze_reset_unfreeze_keeps_the_auto_reset_episodes():
     assert int((a[2] | a[3]).sum()) > 256  # every env went through several auto-resets
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name,n", [("CartPoleSwingUp", 1), ("CartPoleSwingUp", 5), ("BoundaryInvertedPendulumSwingUp", 1), ("HopperRunning", 1), ("HalfCheetahRunning", 3)])
+def test_step_host_equals_step_plus_get_obs(name, n):
+    """emei_step_host (round 4): the single-launch path with its polled completion word (one env of the 4-state family) and the
+    step + emei_get_obs + synchronise path (several envs, the bodies) return what emei_step / emei_get_obs return, bit for bit,
+    over 40 steps with auto-reset and a TimeLimit of 7 (resets inside the window: the float64 observation is then the NEW episode's)."""
+    from emei_amd.engine import Engine
+
+    rng = np.random.default_rng(9)
+    kw = dict(max_episode_steps=7, seed=4, init_noise=5e-3 if "CartPole" not in name else 0.0)
+    a_eng, b_eng = Engine(name, n, **kw), Engine(name, n, **kw)
+    a_eng.reset(4), b_eng.reset(4)
+    for t in range(40):
+        if a_eng.act_dim == 0:
+            act = rng.integers(0, 2, n)
+            dev = torch.as_tensor(act, device=b_eng.device)
+        else:
+            act = rng.uniform(-1, 1, (n,) if a_eng.act_dim == 1 else (n, a_eng.act_dim)).astype(np.float32)
+            dev = torch.as_tensor(act, device=b_eng.device)
+        o64, o32, rew, done = a_eng.step_host(act, auto_reset=True)
+        obs, r, d = b_eng.step(dev, auto_reset=True)
+        assert np.array_equal(o32, obs.cpu().numpy()) and np.array_equal(rew, r.cpu().numpy()) and np.array_equal(done, d.cpu().numpy())
+        assert np.array_equal(o64, b_eng.get_obs().cpu().numpy())
+    assert (np.asarray(done) >= 0).all()
