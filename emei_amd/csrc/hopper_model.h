@@ -34,6 +34,9 @@ namespace hopper {
 
 constexpr int NV = 6, NL = 4;
 enum { L_FOOT = 0, L_LEG = 1, L_THIGH = 2, L_TORSO = 3, P_X = 4, P_Z = 5 };
+// geom g (XML order torso, thigh, leg, foot: xml:18,22,26,30) lies on chain link kGeomLink[g]: make_model, the contact rows and the
+// constants export all read this table
+constexpr int kGeomLink[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
 
 struct Model {
     double sx[NL], sz[NL], diag[NL];  // mass-moment vector (link frame) and constant diagonal inertia per link
@@ -73,6 +76,15 @@ __device__ __forceinline__ V2<R> rot_lit(R c, R s, double ax, double az) {
 // the XML-level tables (hand-typed from hopper.xml; pinned to the file by tests/test_model_constants.py through
 // emei_model_constants) and the capsule masses / inertias MuJoCo's compiler derives (inertiafromgeom, density 1000)
 constexpr double kCtrlLo = -1.0, kCtrlHi = 1.0;  // motors: ctrlrange="-1.0 1.0" (xml:37-39)
+// The three leg hinges turn about -y (axis="0 -1 0", xml:21,25,29): theta_k = kHingeSign * (phi_child - phi_parent).  Every place
+// the dynamics use that relation goes through hs() (exact: a sign flip the compiler folds into its neighbour), and
+// emei_model_constants exports THIS constant, so the XML pin (tests/test_model_constants.py) sees the sign the code runs with.
+constexpr double kHingeSign = -1.0;
+template <typename T>
+__host__ __device__ constexpr T hs(T x) {
+    return kHingeSign < 0 ? -x : x;
+}
+constexpr double kJointStiffness[3] = {0.0, 0.0, 0.0};  // no `stiffness` on the leg joints (xml:5,21,25,29); a non-zero entry adds -k theta
 constexpr double kSolrefTc = 0.02;               // geom solref ".02 1" (xml:6); joint limits: MuJoCo's default (.02 1)
 struct HopperLinks {
     // links in chain order foot, leg, thigh, torso.  Link frames sit at the joint anchors (world at qpos0):
@@ -122,9 +134,8 @@ constexpr Model make_model(double dt) {
     m.mtot = sub[NL - 1], m.gravity = 9.81, m.z0 = K.torso_z - K.z_ref;  // body pos z 1.25, rootz ref 1.25 (:16)
     const double lo[3] = {-150 * deg, -150 * deg, -45 * deg}, hi[3] = {0, 0, 45 * deg};  // :21,25,29
     for (int k = 0; k < 3; ++k) m.damp[k] = 1.0, m.arm[k] = 1.0, m.lo[k] = lo[k], m.hi[k] = hi[k], m.gear[k] = 200.0;  // :5,37-39
-    const int geom_link[4] = {L_TORSO, L_THIGH, L_LEG, L_FOOT};
     for (int g = 0; g < 4; ++g) {
-        const int b = geom_link[g];
+        const int b = kGeomLink[g];
         const H2 ax = hrot(gang[b], {0, 1});
         m.geom_end[2 * g][0] = gc[b].x - half[b] * ax.x, m.geom_end[2 * g][1] = gc[b].z - half[b] * ax.z;
         m.geom_end[2 * g + 1][0] = gc[b].x + half[b] * ax.x, m.geom_end[2 * g + 1][1] = gc[b].z + half[b] * ax.z;
@@ -172,16 +183,16 @@ inline int xml_constants(double* out) {
         for (double v : row) out[n++] = v;
     }
     for (int g = 0; g < 4; ++g) {  // geom order torso, thigh, leg, foot; body index in XML order
-        const double row[7] = {(double)g, m.geom_end[2 * g][0], m.geom_end[2 * g][1], m.geom_end[2 * g + 1][0], m.geom_end[2 * g + 1][1],
+        const double row[7] = {(double)(L_TORSO - kGeomLink[g]) /* body index in XML order */, m.geom_end[2 * g][0], m.geom_end[2 * g][1], m.geom_end[2 * g + 1][0], m.geom_end[2 * g + 1][1],
                                m.radius[g], m.friction[g]};
         for (double v : row) out[n++] = v;
     }
     for (int k = 0; k < 3; ++k) {
-        const double row[6] = {0.0 /* no joint stiffness */, m.damp[k], m.arm[k], m.lo[k], m.hi[k], m.gear[k]};
+        const double row[6] = {kJointStiffness[k], m.damp[k], m.arm[k], m.lo[k], m.hi[k], m.gear[k]};
         for (double v : row) out[n++] = v;
     }
     const double tail[13] = {m.margin, kSolrefTc, m.c_dmin, m.c_dmax, m.c_width, kSolrefTc, m.l_dmin, m.l_dmax, m.l_width, kCtrlLo, kCtrlHi,
-                             K.z_ref, -1.0 /* leg hinges about -y */};
+                             K.z_ref, kHingeSign};
     for (double v : tail) out[n++] = v;
     return n;
 }
@@ -209,7 +220,7 @@ constexpr InvWeights hopper_invweights() {
     InvWeights w{};
     for (int k = 0; k < 3; ++k) {
         double J[NV] = {};
-        J[jc[k]] = -1, J[jp[k]] = 1;  // theta_k = -(phi_child - phi_parent): hinges about -y
+        J[jc[k]] = kHingeSign, J[jp[k]] = -kHingeSign;  // theta_k = kHingeSign (phi_child - phi_parent)
         w.dof[k] = ce::spd_quad<NV>(A, J);
     }
     for (int b = 0; b < NL; ++b) {
@@ -254,7 +265,7 @@ constexpr CapsuleAxis capsule_axis(int g) {
 // (MuJoCo emits up to two contacts for exactly parallel capsules: outside the joint ranges for these pairs, not reproduced).
 template <int PAIR, typename R>
 __device__ __forceinline__ bool capsule_pair(const R (&cs)[NL], const R (&sn)[NL], const V2<R> (&org)[NL], R& dist, V2<R>& n, V2<R>& p) {
-    constexpr int G1 = kPairGeom[PAIR][0], G2 = kPairGeom[PAIR][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
+    constexpr int G1 = kPairGeom[PAIR][0], G2 = kPairGeom[PAIR][1], LA = kGeomLink[G1], LB = kGeomLink[G2];
     constexpr CapsuleAxis c1 = capsule_axis(G1), c2 = capsule_axis(G2);
     constexpr double r1 = kGeom.radius[G1], r2 = kGeom.radius[G2], reach = r1 + r2 + kGeom.margin;
     const V2<R> o1 = rot_lit(cs[LA], sn[LA], c1.cx, c1.cz), a1 = rot_lit(cs[LA], sn[LA], c1.ax, c1.az);
@@ -290,7 +301,7 @@ __device__ __forceinline__ bool capsule_pair(const R (&cs)[NL], const R (&sn)[NL
 // p - org_LB, the link vectors D_a in between, org_(LA-1) - p.
 template <int PAIR, typename R>
 __device__ __forceinline__ void pair_row(const V2<R> (&org)[NL], const V2<R> (&D)[NL], V2<R> n, V2<R> p, R (&J)[NV]) {
-    constexpr int LA = L_TORSO - kPairGeom[PAIR][0], LB = L_TORSO - kPairGeom[PAIR][1];
+    constexpr int LA = kGeomLink[kPairGeom[PAIR][0]], LB = kGeomLink[kPairGeom[PAIR][1]];
 #pragma unroll
     for (int i = 0; i < NV; ++i) J[i] = R(0);
     J[LB] = dotperp(n, V2<R>{p.x - org[LB].x, p.z - org[LB].z});
@@ -340,9 +351,9 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     // absolute angles / rates down the chain (hinges about -y)
     R phi[NL], om[NL];
     phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
-    phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
-    phi[L_LEG] = phi[L_THIGH] - q[4], om[L_LEG] = om[L_THIGH] - v[4];
-    phi[L_FOOT] = phi[L_LEG] - q[5], om[L_FOOT] = om[L_LEG] - v[5];
+    phi[L_THIGH] = phi[L_TORSO] + hs(q[3]), om[L_THIGH] = om[L_TORSO] + hs(v[3]);
+    phi[L_LEG] = phi[L_THIGH] + hs(q[4]), om[L_LEG] = om[L_THIGH] + hs(v[4]);
+    phi[L_FOOT] = phi[L_LEG] + hs(q[5]), om[L_FOOT] = om[L_LEG] + hs(v[5]);
     R cs[NL], sn[NL], w2[NL];
     V2<R> S[NL], D[NL];
 #pragma unroll
@@ -384,9 +395,10 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);  // ctrlrange +-1 (xml:37-39)
-        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
-        f[jc[k]] -= tau;
-        f[jp[k]] += tau;
+        R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
+        if (kJointStiffness[k] != 0.0) tau -= (R)kJointStiffness[k] * q[3 + k];  // compile-time false for this model
+        f[jc[k]] += hs(tau);  // generalised force of a joint torque on the absolute angles: d theta / d phi_child = kHingeSign
+        f[jp[k]] -= hs(tau);
         const R e = (R)kGeom.arm[k] + hd * (R)kGeom.damp[k];  // armature + implicit damping on theta_k
         A[jc[k]][jc[k]] += e;
         A[jp[k]][jp[k]] += e;
@@ -414,7 +426,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
             R y[NV], yd[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) y[i] = R(0);
-            y[C] = -J, y[P] = J;
+            y[C] = hs(J), y[P] = -hs(J);
             ldl_forward<C>(A, y);
             R Aii = R(0), acur = R(0);
 #pragma unroll
@@ -442,7 +454,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     u[P_X] = v[0], u[P_Z] = v[1];
     // one capsule end sphere against the floor; geom order torso, thigh, leg, foot (two ends each)
     auto contact = [&](auto pt_c) __attribute__((always_inline)) {
-        constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+        constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = kGeomLink[gi];
         const V2<R> e = rot(cs[LNK], sn[LNK], (R)kGeom.geom_end[pt][0], (R)kGeom.geom_end[pt][1]);
         const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
         if (dist < (R)kGeom.margin) {
@@ -487,7 +499,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
     contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
     // capsule against capsule: one frictionless row per pair, after the floor points (oracle order)
     auto pair = [&](auto pc) __attribute__((always_inline)) {
-        constexpr int P = decltype(pc)::value, LA = L_TORSO - kPairGeom[P][0], LB = L_TORSO - kPairGeom[P][1];
+        constexpr int P = decltype(pc)::value, LA = kGeomLink[kPairGeom[P][0]], LB = kGeomLink[kPairGeom[P][1]];
         R dist;
         V2<R> n, p;
         if (capsule_pair<P>(cs, sn, org, dist, n, p)) {
@@ -517,7 +529,7 @@ __device__ __forceinline__ void accel(const R (&q)[NV], const R (&v)[NV], const 
 
     // ---- back to joint coordinates
     qacc[0] = acc[P_X], qacc[1] = acc[P_Z], qacc[2] = acc[L_TORSO];
-    qacc[3] = acc[L_TORSO] - acc[L_THIGH], qacc[4] = acc[L_THIGH] - acc[L_LEG], qacc[5] = acc[L_LEG] - acc[L_FOOT];
+    qacc[3] = hs(acc[L_THIGH] - acc[L_TORSO]), qacc[4] = hs(acc[L_LEG] - acc[L_THIGH]), qacc[5] = hs(acc[L_FOOT] - acc[L_LEG]);
 }
 
 // y = A x, A symmetric in its lower triangle
@@ -548,9 +560,9 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     EMEI_MARK(nw_trig);
     R phi[NL], om[NL];
     phi[L_TORSO] = q[2], om[L_TORSO] = v[2];
-    phi[L_THIGH] = phi[L_TORSO] - q[3], om[L_THIGH] = om[L_TORSO] - v[3];
-    phi[L_LEG] = phi[L_THIGH] - q[4], om[L_LEG] = om[L_THIGH] - v[4];
-    phi[L_FOOT] = phi[L_LEG] - q[5], om[L_FOOT] = om[L_LEG] - v[5];
+    phi[L_THIGH] = phi[L_TORSO] + hs(q[3]), om[L_THIGH] = om[L_TORSO] + hs(v[3]);
+    phi[L_LEG] = phi[L_THIGH] + hs(q[4]), om[L_LEG] = om[L_THIGH] + hs(v[4]);
+    phi[L_FOOT] = phi[L_LEG] + hs(q[5]), om[L_FOOT] = om[L_LEG] + hs(v[5]);
     R cs[NL], sn[NL], w2[NL];
     V2<R> S[NL], D[NL];
 #pragma unroll
@@ -600,9 +612,10 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const R c = ctrl[k] < R(kCtrlLo) ? R(kCtrlLo) : (ctrl[k] > R(kCtrlHi) ? R(kCtrlHi) : ctrl[k]);
-        const R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
-        f[jc[k]] -= tau;
-        f[jp[k]] += tau;
+        R tau = (R)kGeom.gear[k] * c - (R)kGeom.damp[k] * v[3 + k];
+        if (kJointStiffness[k] != 0.0) tau -= (R)kJointStiffness[k] * q[3 + k];  // compile-time false for this model
+        f[jc[k]] += hs(tau);  // generalised force of a joint torque on the absolute angles: d theta / d phi_child = kHingeSign
+        f[jp[k]] -= hs(tau);
     }
     V2<R> org[NL];
     org[L_TORSO] = V2<R>{q[0], (R)kGeom.z0 + q[1]};
@@ -616,7 +629,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     for (int k = 0; k < 3; ++k) rows |= ((q[3 + k] < (R)kGeom.lo[k]) | (q[3 + k] > (R)kGeom.hi[k])) ? (1u << k) : 0u;
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
-        const int gi = pt / 2, L = L_TORSO - gi;
+        const int gi = pt / 2, L = kGeomLink[gi];
         const R ez = rot_lit(cs[L], sn[L], kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]).z;
         rows |= (org[L].z + ez - (R)kGeom.radius[gi] < (R)kGeom.margin) ? (1u << (3 + pt)) : 0u;
     }
@@ -694,12 +707,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
                     const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
                     const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
-                    const R x = J * (a[P] - a[C]) - aref;
+                    const R x = J * hs(a[C] - a[P]) - aref;
                     if (x < R(0)) {
                         flags |= 1u << k;
                         const R Dw = div_r(imp, (R(1) - imp) * (R)kInvW.dof[k]);
                         const R t = Dw * x * J;
-                        gr[P] += t, gr[C] -= t;
+                        gr[C] += hs(t), gr[P] -= hs(t);
                         A[C][C] += Dw, A[P][P] += Dw, A[P][C] -= Dw;  // P > C
                     }
                 }
@@ -707,7 +720,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             limit(std::integral_constant<int, 0>{}), limit(std::integral_constant<int, 1>{}), limit(std::integral_constant<int, 2>{});
             EMEI_MARK(nw_contacts);
             auto contact = [&](auto pt_c) __attribute__((always_inline)) {
-                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = kGeomLink[gi];
                 if (rows & (1u << (3 + pt))) {
                     EMEI_STAT_WAVE(4);
                     EMEI_STAT_LANE(5);
@@ -766,7 +779,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact(integral_constant<int, 6>{}), contact(integral_constant<int, 7>{});
             EMEI_MARK(hp_pairs);
             auto pair = [&](auto pc) __attribute__((always_inline)) {
-                constexpr int P = decltype(pc)::value, G1 = kPairGeom[P][0], G2 = kPairGeom[P][1], LA = L_TORSO - G1, LB = L_TORSO - G2;
+                constexpr int P = decltype(pc)::value, G1 = kPairGeom[P][0], G2 = kPairGeom[P][1], LA = kGeomLink[G1], LB = kGeomLink[G2];
                 if (rows & (1u << (11 + P))) {
                     EMEI_STAT_WAVE(4);
                     R dist, J[NV];
@@ -829,12 +842,12 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
                     const R dist = lower ? th - (R)kGeom.lo[k] : (R)kGeom.hi[k] - th, J = lower ? R(1) : R(-1);
                     const R imp = impedance(dist, (R)kGeom.l_dmin, (R)kGeom.l_dmax, (R)(1.0 / kGeom.l_width));
                     const R aref = -(R)m.lB * (J * vk) - (R)m.lK * imp * dist;
-                    again |= (J * (a[P] - a[C]) - aref < R(0)) ? (1u << k) : 0u;
+                    again |= (J * hs(a[C] - a[P]) - aref < R(0)) ? (1u << k) : 0u;
                 }
             };
             limit2(std::integral_constant<int, 0>{}), limit2(std::integral_constant<int, 1>{}), limit2(std::integral_constant<int, 2>{});
             auto contact2 = [&](auto pt_c) __attribute__((always_inline)) {
-                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = L_TORSO - gi;
+                constexpr int pt = decltype(pt_c)::value, gi = pt / 2, LNK = kGeomLink[gi];
                 if (rows & (1u << (3 + pt))) {
                     const V2<R> e = rot_lit(cs[LNK], sn[LNK], kGeom.geom_end[pt][0], kGeom.geom_end[pt][1]);
                     const R dist = org[LNK].z + e.z - (R)kGeom.radius[gi];
@@ -862,7 +875,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
             contact2(integral_constant<int, 3>{}), contact2(integral_constant<int, 4>{}), contact2(integral_constant<int, 5>{});
             contact2(integral_constant<int, 6>{}), contact2(integral_constant<int, 7>{});
             auto pair2 = [&](auto pc) __attribute__((always_inline)) {
-                constexpr int P = decltype(pc)::value, LA = L_TORSO - kPairGeom[P][0], LB = L_TORSO - kPairGeom[P][1];
+                constexpr int P = decltype(pc)::value, LA = kGeomLink[kPairGeom[P][0]], LB = kGeomLink[kPairGeom[P][1]];
                 if (rows & (1u << (11 + P))) {
                     R dist, J[NV];
                     V2<R> n, p;
@@ -910,7 +923,7 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     }
     EMEI_MARK(nw_out);
     qacc[0] = a[P_X], qacc[1] = a[P_Z], qacc[2] = a[L_TORSO];
-    qacc[3] = a[L_TORSO] - a[L_THIGH], qacc[4] = a[L_THIGH] - a[L_LEG], qacc[5] = a[L_LEG] - a[L_FOOT];
+    qacc[3] = hs(a[L_THIGH] - a[L_TORSO]), qacc[4] = hs(a[L_LEG] - a[L_THIGH]), qacc[5] = hs(a[L_FOOT] - a[L_LEG]);
 }
 
 }  // namespace hopper
