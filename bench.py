@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--gather", default=None, choices=["final", "per_chunk", "per_step"],
                     help="what the observation return exchanges across ranks (default: per_chunk when --gpus > 1, final otherwise)")
     ap.add_argument("--chunk", type=int, default=125, help="steps per launch / per all-gather with --gather per_chunk")
+    ap.add_argument("--exchange", default="collective", choices=["collective", "direct"],
+                    help="how the observation return crosses ranks: the backend's all-gather, or 1-hop transfers to and from every "
+                         "peer at once (the xGMI mesh has a link per peer)")
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
     ap.add_argument("--integrator", default=None, choices=["euler", "semi_implicit_euler", "rk4"],
@@ -256,7 +259,8 @@ def main():
     chunk = a.chunk if T % a.chunk == 0 else T
     sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
                         rank=rank, world=world, device=local_rank, seed=0,
-                        integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk, solver=a.solver)
+                        integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk, solver=a.solver,
+                        exchange_algo=a.exchange)
     desc = w["desc"]
     if sharded_cartpole and a.workload == "cartpole_swingup" and N == MULTI_GPU_SHARD:
         desc = (f"CartPoleSwingUp-v0, {world * N} parallel envs sharded {world}xMI355X ({N} per GPU) with RCCL all-gather of obs"
@@ -334,7 +338,7 @@ def main():
                    "real_time_scale": w["dt"], "settle_ms_before_warmup": a.settle_ms, "integrator": a.integrator or w.get("integrator", "euler"),
                    "constraint_solver": a.solver if a.workload in ("cheetah", "hopper") else "n/a (at most one constraint row)", "api": f"emei_rollout ({'one launch per horizon' if sr.n_chunks == 1 else f'{sr.n_chunks} launches of {sr.chunk} steps per horizon'}, device auto-reset)",
                    "env_steps_per_bench_step": world * N * T, "action_dtype": sr.action_dtype_name,
-                   "gather": gather, "chunk_steps": sr.chunk,
+                   "gather": gather, "chunk_steps": sr.chunk, "exchange": a.exchange if world > 1 else "n/a (1 GPU)",
                    "obs_allgather": ({"final": "last [n,obs_dim] observation of each pass",
                                       "per_chunk": f"the whole [T,n,obs_dim] observation return, one all-gather per {sr.chunk}-step chunk",
                                       "per_step": "the [n,obs_dim] observation of every env-step, one all-gather per step"}[gather]

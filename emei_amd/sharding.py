@@ -17,11 +17,39 @@ def shard_bounds(n_global, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_obs(local_obs, group=None, out=None):
-    """All-gather equal-sized observation shards ([n, d] or [rows, n, d]) rank-major: `out` is [world * n, d], or
-    [world, rows, n, d] when given (rank r's block at out[r]; for [n, d] shards rank-major IS global env order)."""
+ALGOS = ("collective", "direct")
+
+
+def _allgather_direct(local_obs, flat, group):
+    """The all-gather as point-to-point transfers: this rank's block goes to EVERY peer and every peer's block comes straight
+    into its place of the receive buffer, all 2 (world - 1) transfers posted as one batch (one RCCL group: they run
+    concurrently).  On MI355X the 8 GPUs of a node are a full xGMI mesh — 7 links per GPU, each to one peer — so every transfer
+    of the batch has a link of its own and nothing is forwarded (a ring all-gather forwards every block world - 2 times over
+    one link per hop); results are identical to the collective (the copies are bit-exact either way)."""
     import torch.distributed as dist
 
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = local_obs.shape[0]
+    src = local_obs.contiguous()
+    flat[rank * rows:(rank + 1) * rows].copy_(src)
+    ops = []
+    for k in range(1, world):  # peers in rotating order: at step k every rank sends to rank + k and receives from rank - k
+        to, frm = (rank + k) % world, (rank - k) % world
+        ops.append(dist.P2POp(dist.isend, src, dist.get_global_rank(group, to) if group is not None else to, group))
+        ops.append(dist.P2POp(dist.irecv, flat[frm * rows:(frm + 1) * rows], dist.get_global_rank(group, frm) if group is not None else frm, group))
+    for w in dist.batch_isend_irecv(ops) if ops else []:
+        w.wait()
+
+
+def allgather_obs(local_obs, group=None, out=None, algo="collective"):
+    """All-gather equal-sized observation shards ([n, d] or [rows, n, d]) rank-major: `out` is [world * n, d], or
+    [world, rows, n, d] when given (rank r's block at out[r]; for [n, d] shards rank-major IS global env order).
+    algo: "collective" = the backend's all-gather (RCCL picks ring / tree itself), "direct" = 1-hop transfers to and from
+    every peer at once (_allgather_direct: the shape of the xGMI mesh)."""
+    import torch.distributed as dist
+
+    if algo not in ALGOS:
+        raise ValueError(f"algo={algo!r}; known: {ALGOS}")
     if not (dist.is_available() and dist.is_initialized()):
         return local_obs
     world = dist.get_world_size(group)
@@ -34,10 +62,16 @@ def allgather_obs(local_obs, group=None, out=None):
     if dist.get_backend(group) == "gloo" and local_obs.is_cuda:
         # rehearsal path only (gloo has no device all-gather): stage through the host
         host = torch.empty(flat.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, local_obs.cpu().contiguous(), group=group)
+        if algo == "direct":
+            _allgather_direct(local_obs.cpu(), host, group)
+        else:
+            dist.all_gather_into_tensor(host, local_obs.cpu().contiguous(), group=group)
         flat.copy_(host)
         return out
-    dist.all_gather_into_tensor(flat, local_obs.contiguous(), group=group)
+    if algo == "direct":
+        _allgather_direct(local_obs, flat, group)
+    else:
+        dist.all_gather_into_tensor(flat, local_obs.contiguous(), group=group)
     return out
 
 
@@ -53,7 +87,10 @@ class ObsExchange:
       receive buffers alternate; gathers are serialised on the comm stream, so buffer b is free again when the
       gather two collectives later starts (a consumer reads it in between)"""
 
-    def __init__(self, world, rows, n, obs_dim, n_slots, device):
+    def __init__(self, world, rows, n, obs_dim, n_slots, device, algo="collective"):
+        if algo not in ALGOS:
+            raise ValueError(f"algo={algo!r}; known: {ALGOS}")
+        self.algo = algo
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.gathered = [torch.empty((world, rows, n, obs_dim), dtype=torch.float32, device=self.device) for _ in range(2)]
@@ -69,13 +106,13 @@ class ObsExchange:
         buf = self.gathered[self.collectives & 1]
         self.collectives += 1
         if not self.cuda:
-            allgather_obs(block, group=group, out=buf)
+            allgather_obs(block, group=group, out=buf, algo=self.algo)
             return buf
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ready)
-            allgather_obs(block, group=group, out=buf)
+            allgather_obs(block, group=group, out=buf, algo=self.algo)
             done = torch.cuda.Event()
             done.record(self._comm)
         self._done[slot] = done
@@ -136,7 +173,7 @@ class ShardedRollout:
 
     def __init__(self, env, envs_per_rank, horizon, freq_rate=1, real_time_scale=0.02, precision="ref", rank=0,
                  world=1, device=0, seed=0, init_noise=None, integrator="euler", gather="final", chunk=None,
-                 force_exchange=False, solver="newton"):
+                 force_exchange=False, solver="newton", exchange_algo="collective"):
         from .engine import Engine
 
         self.env, self.n, self.horizon, self.rank, self.world = env, int(envs_per_rank), int(horizon), rank, world
@@ -149,6 +186,7 @@ class ShardedRollout:
             raise ValueError(f"chunk {self.chunk} must divide the horizon {self.horizon}")
         self.n_chunks = self.horizon // self.chunk
         self.exchanging = world > 1 or bool(force_exchange)
+        self.exchange_algo = exchange_algo
         if init_noise is None:
             init_noise = 0.1 if env == "HalfCheetahRunning" else 5e-3
         self.engine = Engine(env, self.n, freq_rate=freq_rate, real_time_scale=real_time_scale, precision=precision,
@@ -201,7 +239,7 @@ class ShardedRollout:
             # a chunk's observation block is gathered straight from the rollout's output slice (slot = chunk index);
             # "final" copies the last row to a one-row staging buffer first (slot 0)
             rows = 1 if self.gather == "final" else K
-            self.xchg = ObsExchange(self.world, rows, self.n, self.obs_dim, self.n_chunks, self.device)
+            self.xchg = ObsExchange(self.world, rows, self.n, self.obs_dim, self.n_chunks, self.device, algo=self.exchange_algo)
             self.gathered = self.xchg.gathered
             self._stage = torch.empty((1, self.n, self.obs_dim), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize()

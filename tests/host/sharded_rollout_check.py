@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=16)
     ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--exchange", default="collective")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -40,7 +41,7 @@ def main():
 
     env, n, T = "CartPoleSwingUp", a.envs, a.horizon
     sr = ShardedRollout(env, n, T, rank=rank, world=world, device=dev, seed=0, gather=a.gather, chunk=a.chunk,
-                        force_exchange=True)
+                        force_exchange=True, exchange_algo=a.exchange)
     sr.make_synthetic_inputs()
     # reference engines: one per rank of the job, all on THIS rank's GPU
     refs = []

@@ -32,3 +32,13 @@ def test_two_ranks_share_the_gpu_over_gloo(gather, chunk):
 def test_one_rank_rccl_group(gather):
     out = _run(1, 29612, "--backend", "nccl", "--gather", gather, "--chunk", "16", "--envs", "65536")
     assert "world=1 backend=nccl" in out
+
+
+@pytest.mark.parametrize("gather", ["per_chunk", "final"])
+def test_direct_exchange(gather):
+    """The point-to-point form of the exchange (sharding._allgather_direct): 2 ranks over gloo (peer blocks checked) and the
+    1-rank RCCL group (no peer: the local copy alone)."""
+    out = _run(2, 29613, "--backend", "gloo", "--gather", gather, "--chunk", "16", "--horizon", "64", "--exchange", "direct")
+    assert "world=2" in out
+    out = _run(1, 29614, "--backend", "nccl", "--gather", gather, "--chunk", "16", "--envs", "65536", "--exchange", "direct")
+    assert "world=1 backend=nccl" in out

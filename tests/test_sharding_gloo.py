@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_per_rank, q):
+def _worker(rank, world, port, n_per_rank, q, algo="collective"):
     sys.path.insert(0, ROOT)
     from emei_amd.sharding import allgather_obs, shard_bounds, synthetic_init_state
 
@@ -35,21 +35,23 @@ def _worker(rank, world, port, n_per_rank, q):
         assert np.array_equal(full[lo:hi], mine)
         local = torch.as_tensor(mine, dtype=torch.float32)
         for _ in range(3):  # repeated collectives, as in a stepping loop
-            gathered = allgather_obs(local)
+            gathered = allgather_obs(local, algo=algo)
         ok = torch.equal(gathered, torch.as_tensor(full, dtype=torch.float32))
+        if algo == "direct":  # the point-to-point form fills the same buffer as the collective, bit for bit
+            ok &= torch.equal(gathered, allgather_obs(local, algo="collective"))
         q.put((rank, bool(ok), tuple(gathered.shape)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])
-def test_allgather_obs(world):
+@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (2, "direct"), (4, "direct"), (3, "direct")])
+def test_allgather_obs(world, algo):
     n = 96
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=90) for _ in range(world))
@@ -59,7 +61,7 @@ def test_allgather_obs(world):
     assert res == [(r, True, (world * n, 4)) for r in range(world)]
 
 
-def _xchg_worker(rank, world, port, q):
+def _xchg_worker(rank, world, port, q, algo="collective"):
     """ObsExchange (the buffer rotation under ShardedRollout.run_pass) on CPU tensors: per-chunk blocks of a
     [T, n, d] return over several passes; every receive buffer must hold every rank's block of that collective."""
     sys.path.insert(0, ROOT)
@@ -69,7 +71,7 @@ def _xchg_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         T, K, n, d = 12, 4, 10, 4
-        x = ObsExchange(world, K, n, d, T // K, "cpu")
+        x = ObsExchange(world, K, n, d, T // K, "cpu", algo=algo)
 
         def block(r, p, c):  # what rank r produces for chunk c of pass p
             return (torch.arange(K * n * d, dtype=torch.float32).reshape(K, n, d) + 1000.0 * r + 100.0 * p + 10.0 * c)
@@ -90,12 +92,12 @@ def _xchg_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])
-def test_obs_exchange_chunks(world):
+@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (4, "direct")])
+def test_obs_exchange_chunks(world, algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_xchg_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_xchg_worker, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=90) for _ in range(world))
