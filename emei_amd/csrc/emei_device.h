@@ -257,28 +257,47 @@ struct TrigPendingF32 {
     float s, c;
 };
 __device__ __forceinline__ TrigPendingF64 sincos_begin_ctx(const TrigCtx& t, double x_any) {
-    const double x = trig_arg(x_any);  // a cold branch in front of the straight-line block
     const double inv_step = 40.74366543152521;                                    // 256 / (2 pi)
     const double H1 = 1.5707963267948966 / 64, H2 = 6.123233995736766e-17 / 64;  // 2pi/256 = H1 + H2
-    TrigPendingF64 p;
-    // nearest integer of x * inv_step without v_rndne + v_cvt: adding 1.5 * 2^52 leaves it in the low mantissa
-    // bits (|x * inv_step| < 2^31 is guaranteed by the |x| <= 1e6 range of the fast path)
-    const double magic = 6755399441055744.0;
-    const double shifted = __builtin_fma(x, inv_step, magic);
-    const double n = shifted - magic;
-    // table index from the low mantissa bits: (k & 255) * 16 + base in two instructions, written out because hipcc turns
-    // the C expression into three (shift, mask with 0xff0, add)
-    static_assert(kTrigTableSize == 256, "the index mask below");
-    uint32_t addr;
-    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, 4, %2" : "=v"(addr) : "v"((uint32_t)__double2loint(shifted)), "s"(t.lds_base));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
-    // x lives on (it is the state's angle): as fma(-n, H1, x) hipcc copies it first (v_mov_b64 + the two-address v_fmac_f64);
-    // the three-address form leaves it where it is
-    double r = fma_vsv(n, -H1, x);
-    r = __builtin_fma(-n, H2, r);
-    const double z = r * r;
-    p.sr = __builtin_fma(r * z, fma_vsv(z, 1.0 / 120, t.c3), r);
-    p.cr = __builtin_fma(z, __builtin_fma(z, fma_vsv(z, -1.0 / 720, t.c4), -0.5), 1.0);
+    auto begin = [&](double x) __attribute__((always_inline)) {
+        TrigPendingF64 p;
+        // nearest integer of x * inv_step without v_rndne + v_cvt: adding 1.5 * 2^52 leaves it in the low mantissa
+        // bits (|x * inv_step| < 2^31 is guaranteed by the |x| <= 1e6 range of the fast path)
+        const double magic = 6755399441055744.0;
+        const double shifted = __builtin_fma(x, inv_step, magic);
+        const double n = shifted - magic;
+        // table index from the low mantissa bits: (k & 255) * 16 + base in two instructions, written out because hipcc turns
+        // the C expression into three (shift, mask with 0xff0, add)
+        static_assert(kTrigTableSize == 256, "the index mask below");
+        uint32_t addr;
+        asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, 4, %2" : "=v"(addr) : "v"((uint32_t)__double2loint(shifted)), "s"(t.lds_base));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(p.e) : "v"(addr));
+        // x lives on (it is the state's angle): as fma(-n, H1, x) hipcc copies it first (v_mov_b64 + the two-address v_fmac_f64);
+        // the three-address form leaves it where it is
+        double r = fma_vsv(n, -H1, x);
+        r = __builtin_fma(-n, H2, r);
+        const double z = r * r;
+        p.sr = __builtin_fma(r * z, fma_vsv(z, 1.0 / 120, t.c3), r);
+        p.cr = __builtin_fma(z, __builtin_fma(z, fma_vsv(z, -1.0 / 720, t.c4), -0.5), 1.0);
+        return p;
+    };
+    // Arguments beyond the fast range are repaired AFTER the fact, in a cold, wave-uniform branch that reduces them and runs
+    // the block again (for the other lanes of such a wave the second run repeats the first bit for bit): reduced up front and
+    // joined in front of one shared copy of the block, the reduced angle and the state's angle need one register, i.e. a
+    // v_mov_b64 of the angle on the hot path of every substep.  The first run of a cold lane reads a valid table slot (the
+    // index is masked) and its garbage is dropped.
+    TrigPendingF64 p = begin(x_any);
+    const bool cold = !(__builtin_fabs(x_any) <= kFastTrigLimitF64);
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {  // wave-uniform entry: see sincos_repair_r
+        // hipcc takes an asm's output for available — and, once dead, for FREE — at once: it would hand the first read's
+        // destination registers to the reduction below while the LDS is still to deliver into them, and the copies it places
+        // at the join would read the second entry before it has arrived.  Both reads are waited for here (cold path only);
+        // sincos_end_ctx's own wait then finds nothing pending.
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.e));
+        const double red = trig_reduce_large(x_any);    // straight-line arithmetic: every lane computes it, cold lanes take it
+        p = begin(cold ? red : x_any);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.e));
+    }
     return p;
 }
 __device__ __forceinline__ void sincos_pin(const TrigPendingF64& p, double& a, double& b) {
@@ -309,15 +328,22 @@ __device__ __forceinline__ void sincos_ctx(const TrigCtx& t, float x, float& s, 
 }
 // every thread of the 256-thread block copies one entry; the barrier must be reached by ALL threads
 // (callers stage the table before any early return)
-// `scale`: an env whose dynamics only ever use m * sin and m * cos stages the table pre-multiplied (InvPend: the
-// pole's mass moment) and saves the two products per substep; 1 = the plain table.
+// `rot_c`, `rot_s`: an env whose dynamics only ever use m sin(x + off) and m cos(x + off) stages the table rotated by
+// its constant offset and pre-multiplied (InvPend: the pole's mass moment and the angle of its centre of mass at theta = 0;
+// rot_c = m cos(off), rot_s = m sin(off)) — the substep then looks its state's angle up as it is and saves the addition
+// and the two products; (1, 0) = the plain table, bit for bit.
 template <int BLOCK = kBlock>
-__device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src, double scale = 1.0) {
+__device__ __forceinline__ void stage_trig_table(SinCosEntry* lds, const SinCosEntry* __restrict__ src, double rot_c = 1.0, double rot_s = 0.0) {
     static_assert(kTrigTableSize % BLOCK == 0, "every thread copies the same number of entries");
 #pragma unroll
     for (int k = 0; k < kTrigTableSize / BLOCK; ++k) {
         SinCosEntry e = src[k * BLOCK + threadIdx.x];
-        if (scale != 1.0) e.s *= scale, e.c *= scale;
+        if (rot_s != 0.0) {
+            const double sn = __builtin_fma(e.s, rot_c, e.c * rot_s), cs = __builtin_fma(e.c, rot_c, -(e.s * rot_s));
+            e.s = sn, e.c = cs;
+        } else if (rot_c != 1.0) {
+            e.s *= rot_c, e.c *= rot_c;
+        }
         lds[k * BLOCK + threadIdx.x] = e;
     }
     __syncthreads();
@@ -348,6 +374,12 @@ __device__ __forceinline__ double flip_sign(double v, uint32_t mask) {
 }
 __device__ __forceinline__ float flip_sign(float v, uint32_t mask) { return __uint_as_float(__float_as_uint(v) ^ mask); }
 
+__device__ __forceinline__ double abs_r(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float abs_r(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double copysign_r(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
+__device__ __forceinline__ float copysign_r(float mag, float sgn) { return __builtin_copysignf(mag, sgn); }
+__device__ __forceinline__ double fmax_r(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fmax_r(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // n / d for O(1) denominators

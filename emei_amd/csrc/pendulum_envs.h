@@ -49,10 +49,12 @@ struct CartPole {
         TrigCtx trig;
     };
     using Action = R;  // force / total_mass
-    __host__ __device__ static constexpr double trig_scale() { return 1.0; }
+    __host__ __device__ static constexpr double trig_rot_c() { return 1.0; }  // the plain table (emei_device.h:stage_trig_table)
+    __host__ __device__ static constexpr double trig_rot_s() { return 0.0; }
     // BASELINE configs[1] / [4] give the staged rollout 1-2 waves per SIMD: registers are free, the spare initial state
     // of the reset path lives in them
     static constexpr bool kSpareInLds = false;
+    static constexpr bool kSpareFlagInVgpr = false;
     static constexpr int kMinWavesPerEU = 1;
     // only the float32 time step reaches the kernel: a small argument block leaves the scalar
     // registers to the polynomial constants of sincos (otherwise they are copied through VGPRs)
@@ -286,15 +288,19 @@ struct InvPend {
     // BASELINE configs[2]: 262 144 envs = 4 waves per SIMD, which only fit with <= 128 registers per lane (and <= 40 KiB
     // of LDS per block): the spare initial state of the reset path goes to LDS, the rollout is compiled for 4 waves
     static constexpr bool kSpareInLds = true;
+    static constexpr bool kSpareFlagInVgpr = true;  // pendulum_kernels.h:maybe_reset
     // The SwingUp variants (BASELINE configs[2] is BoundarySwingUp) are compiled for 4 waves per SIMD (<= 128 registers).  The
     // Balancing variants carry the two-row limit solve of the hinge stop (ip_limit_rows, a cold path): under the 128-register
     // cap it spilled 12-20 B to scratch (scratch traffic shares vmcnt with the staged tile loads: tests/test_isa_guards.py),
     // so they are compiled for 3 waves per SIMD — at 262 144 envs their fourth wave queues instead of being resident.
     static constexpr int kMinWavesPerEU = VARIANT >= 2 ? 4 : 3;
     __device__ static constexpr const IpModel& km() { return VARIANT >= 2 ? kIpHanging : kIpUpright; }
-    // The dynamics only use mpr * sin(phi) and mpr * cos(phi): the float64 kernels stage the {sin,cos} table
-    // pre-multiplied by the pole's mass moment (emei_device.h:stage_trig_table), the carry holds the products
-    __host__ __device__ static constexpr double trig_scale() { return kF64 ? ip_make_model(VARIANT >= 2).mpr : 1.0; }
+    // The dynamics only use mpr * sin(phi) and mpr * cos(phi), phi = theta + phi_off: the float64 kernels stage the {sin,cos}
+    // table rotated by phi_off and pre-multiplied by the pole's mass moment (emei_device.h:stage_trig_table), look theta
+    // itself up (trig_angle) and the carry holds the products
+    __host__ __device__ static constexpr double trig_rot_c() { return kF64 ? ip_make_model(VARIANT >= 2).mpr * ip_make_model(VARIANT >= 2).cos_off : 1.0; }
+    __host__ __device__ static constexpr double trig_rot_s() { return kF64 ? ip_make_model(VARIANT >= 2).mpr * ip_make_model(VARIANT >= 2).sin_off : 0.0; }
+    __device__ __forceinline__ static R trig_angle(R theta) { return kF64 ? theta : theta + (R)km().phi_off; }
     struct Carry {
         R sn, cs;  // mpr * sin(phi), mpr * cos(phi), phi = theta + phi_off
         TrigCtx trig;
@@ -319,7 +325,9 @@ struct InvPend {
     // ctrllimited motor (xml:23): the actuator force is constant over the substeps of a step.  The clamp runs in
     // float32 (the bounds are exact there): one v_med3_f32
     __device__ __forceinline__ static Action decode(RawAction a) {
-        const float u = __builtin_fminf(__builtin_fmaxf(a, (float)km().ctrl_lo), (float)km().ctrl_hi);
+        // (the builtin: fminf(fmaxf()) compiles to three instructions, the first a canonicalising v_max_f32 a, a; a NaN action
+        // gives ctrl_lo either way — v_med3_f32 returns min3 when an input is NaN)
+        const float u = __builtin_amdgcn_fmed3f(a, (float)km().ctrl_lo, (float)km().ctrl_hi);
         return (R)km().gear * (R)u;
     }
     template <typename T>
@@ -331,7 +339,7 @@ struct InvPend {
     }
 
     __device__ __forceinline__ static void prime(const R s[4], Carry& c, const Params&) {
-        sincos_ctx(c.trig, s[1] + (R)km().phi_off, c.sn, c.cs);
+        sincos_ctx(c.trig, trig_angle(s[1]), c.sn, c.cs);
         if (!kF64) c.sn *= (R)km().mpr, c.cs *= (R)km().mpr;
     }
     __device__ __forceinline__ static void after_reset(const R[4], Carry&) {}  // the carry is trigonometry only
@@ -351,7 +359,7 @@ struct InvPend {
         s[0] = fma_r(dt, v_old, x_old);
         s[1] = fma_r(dt, om_old, s[1]);
         R P = c.sn, Q = c.cs;
-        auto pending = sincos_begin_ctx(c.trig, s[1] + (R)m.phi_off);
+        auto pending = sincos_begin_ctx(c.trig, trig_angle(s[1]));
         sincos_pin(pending, P, Q);
         const R f1 = fma_r(P, om_old * om_old, gu);
         const R gP = (R)m.gravity * P;  // f2
@@ -359,40 +367,45 @@ struct InvPend {
         R a0 = fma_r((R)m.M22, f1, -(Q * gP)) * idet;
         R a1 = fma_r((R)m.M11, gP, -(Q * f1)) * idet;
         // Soft slider-limit constraint (MuJoCo joint limit, default solref / solimp).  The rail is symmetric (xml:14,
-        // range -2 2): the violated side, if any, is the one x is on, and its distance is x_hi - |x|.
+        // range -2 2): the violated side, if any, is the one x is on, and its distance is x_hi - |x| < 0.
         static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
-        const R dist = (R)m.x_hi - fabs(x_old);
+        const bool beyond = abs_r(x_old) > (R)m.x_hi;
         EMEI_STAT_WAVE(19);  // substeps (waves)
-        // The slider row alone, in closed form (the hot path's limit block)
+        // The slider row alone, in closed form (the hot path's limit block: config 3 runs it in 55 % of a wave's substeps for
+        // 1.7 % of the lanes, so every instruction here is worth half an instruction of the substep itself).
+        //   J = -sign(x) (+1 at the lower stop), dist = x_hi - |x|, imp = impedance(|dist| / width),
+        //   aref = -K imp dist - B J v,  R = (1 - imp) / imp invw,  A = J M^-1 J' = M22 / det
+        //   force = max(0, (aref - J a0) / (A + R)),  a += M^-1 J' force
+        // written with aref - J a0 = J (-B v - a0) - K imp dist so that J only ever multiplies (a +-1.0 factor of an fma, not
+        // sign-bit surgery on copies), with -K imp dist = fma(K imp, |x|, -K imp x_hi) (exact: x_hi - |x| is, by Sterbenz), and
+        // with the force clamped by a maximum instead of a branch.
         auto slider_row = [&]() __attribute__((always_inline)) {
             EMEI_STAT_WAVE(20);  // ... with the limit block
             EMEI_STAT_LANE(21);  // lanes beyond the rail
-            const uint32_t jm = x_old < R(0) ? 0u : 0x80000000u;  // J = +1 at the lower stop, -1 at the upper one
-            const R A = (R)m.M22 * idet;                           // J M^-1 J^T
-            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost
-            // always — then the wave skips the polynomial)
-            // force = (aref - J a0) / (A + (1 - imp) / imp * invw) = (aref - J a0) imp / (A imp + (1 - imp) invw): one division.
-            // The same expression in both branches, so that a lane's bits do not depend on the branch its WAVE took (with
-            // y = 1 the polynomial branch gives imp == dmax exactly); with the constant, -limK imp and (1 - imp) invw leave
-            // the substep loop.
-            auto force_of = [&](R imp) __attribute__((always_inline)) {
-                const R aref = fma_r(-(R)p.limK * imp, dist, -(R)p.limB * flip_sign(v_old, jm));
-                return (aref - flip_sign(a0, jm)) * imp * rcp1_r(fma_r(A, imp, (R(1) - imp) * (R)m.invw));
+            const R nJ = copysign_r(R(1), x_old);  // -J
+            const R n1 = fma_r((R)p.limB, v_old, a0);  // aref - J a0 = nJ (B v + a0) - K imp dist
+            const R A = (R)m.M22 * idet;
+            auto finish = [&](R Kimp, R Kimp_xhi, R Rr) __attribute__((always_inline)) {
+                const R num = fma_r(nJ, n1, fma_r(Kimp, abs_r(x_old), -Kimp_xhi));  // -K imp dist, dist = x_hi - |x|
+                const R force = fmax_r(num * rcp1_r(A + Rr), R(0));
+                const R g = (nJ * force) * idet;  // M^-1 J' force = -(M22, -Q) g
+                a0 = fma_r(-(R)m.M22, g, a0);
+                a1 = fma_r(Q, g, a1);
             };
-            static_assert(0.9 + (0.95 - 0.9) == 0.95 && m.dmin == 0.9 && m.dmax == 0.95, "imp(y = 1) == dmax bit for bit");
-            const R xx = -dist * (R)m.inv_width;
-            R force;
-            if (__builtin_expect(__ballot(xx < R(1)) != 0ull, 0)) {
-                const R u1 = R(1) - xx;
-                const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
-                force = force_of(fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin));
+            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost always —
+            // then the wave skips the polynomial).  A lane's bits must not depend on the branch its WAVE took: a lane beyond the
+            // width takes the constants in either branch (`full` is the same predicate as the ballot's).
+            constexpr double kRfull = (1.0 - m.dmax) / m.dmax * m.invw;
+            const R Kfull = (R)p.limK * (R)m.dmax, Kfull_xhi = Kfull * (R)m.x_hi;
+            const bool full = !(abs_r(x_old) < (R)(m.x_hi + m.width));
+            if (__builtin_expect(__ballot(!full) != 0ull, 0)) {
+                const R xx = (abs_r(x_old) - (R)m.x_hi) * (R)m.inv_width, u1 = R(1) - xx;
+                const R y = xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1));
+                const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+                const R Kimp = full ? Kfull : (R)p.limK * imp;
+                finish(Kimp, full ? Kfull_xhi : Kimp * (R)m.x_hi, full ? (R)kRfull : (R(1) - imp) * (R)m.invw * rcp1_r(imp));
             } else {
-                force = force_of((R)m.dmax);
-            }
-            if (force > R(0)) {
-                const R Jf = flip_sign(force, jm);
-                a0 = fma_r(A, Jf, a0);
-                a1 = fma_r(-(Q * idet), Jf, a1);
+                finish(Kfull, Kfull_xhi, (R)kRfull);
             }
         };
         // Balancing variants: the hinge's +-90 degree stop (a post-terminal state).  A wave with such a lane takes a cold,
@@ -405,15 +418,15 @@ struct InvPend {
         }
         if (__builtin_expect(VARIANT < 2 && __ballot(hinge) != 0ull, 0)) {
             if (hinge) ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
-            else if (dist < R(0)) slider_row();
-        } else if (dist < R(0)) {
+            else if (beyond) slider_row();
+        } else if (beyond) {
             slider_row();
         }
         s[2] = fma_r(dt, a0, v_old);  // MuJoCo Euler on qvel (no joint damping in this model)
         s[3] = fma_r(dt, a1, om_old);
         sincos_end_ctx(pending, a0, a1, c.sn, c.cs);
         if (!kF64) c.sn *= (R)m.mpr, c.cs *= (R)m.mpr;
-        sincos_post_ctx(s[1] + (R)m.phi_off, c.sn, c.cs);
+        sincos_post_ctx(trig_angle(s[1]), c.sn, c.cs);
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
@@ -428,13 +441,21 @@ struct InvPend {
         return c.cs * (R)(km().cos_off * km().inv_mpr) + c.sn * (R)(km().sin_off * km().inv_mpr);
     }
     __device__ __forceinline__ static R reward(const R o[4], const Carry& c, const Params& p) {
-        if (VARIANT >= 2) return (R(1) - cos_theta(c, p)) / R(2);  // inverted_pendulum.py:139-142,174-177
-        return R(1);                                                // :73-74,103-104
+        // inverted_pendulum.py:139-142,174-177: (1 - cos theta) / 2 with cos theta = cs k1 + sn k2 (cos_theta below), the
+        // halving and the sign folded into the two constants: two fused multiply-adds instead of five operations
+        if (VARIANT >= 2)
+            return fma_r(c.cs, (R)(-0.5 * km().cos_off * km().inv_mpr), fma_r(c.sn, (R)(-0.5 * km().sin_off * km().inv_mpr), R(0.5)));
+        return R(1);  // :73-74,103-104
     }
-    __device__ __forceinline__ static R reward_exact(const R o[4], const Carry& c, const Params& p) { return reward(o, c, p); }
+    // the stateless entry points (emei_reward_io on float64 rows) keep the expression as the reference writes it
+    __device__ __forceinline__ static R reward_exact(const R o[4], const Carry& c, const Params& p) {
+        return VARIANT >= 2 ? (R(1) - cos_theta(c, p)) / R(2) : R(1);
+    }
     __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const Params& p) {
-        bool fin = finite_r(o[0]) & finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
         bool inx = ((R)km().x_lo < o[0]) & (o[0] < (R)km().x_hi);
+        // np.isfinite(obs).all(); where `inx` is part of the test it already fails for a NaN / infinite x
+        bool fin = finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
+        if (VARIANT == 0 || VARIANT == 2) fin &= finite_r(o[0]);
         R y = cos_theta(c, p);
         bool notdone;
         if (VARIANT == 0) notdone = (y >= R(0.9)) & fin;           // :76-79

@@ -43,7 +43,7 @@ template <class Env, typename ActT, bool FULL>
 __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<Env> a) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, a.trig, Env::trig_scale());
+    stage_trig_table(trig_s, a.trig, Env::trig_rot_c(), Env::trig_rot_s());
     const ActT* __restrict__ actions = (const ActT*)a.actions;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     __shared__ R spare_s[kLdsSpare ? kWavesPerBlock : 1][6][kLdsSpare ? kWave : 1];
 
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, a.trig, Env::trig_scale());
+    stage_trig_table(trig_s, a.trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
     if (i >= a.n) return;
@@ -241,17 +241,24 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     float sp_e0 = 0.f, sp_e1 = 0.f;  // the non-trigonometric part of the spare's carry (Env::save_extra / load_extra)
     const unsigned long long reset_mask = auto_reset ? ~0ull : 0ull;
     // which lanes hold a spare: a wave-uniform 64-bit mask in scalar registers (ballot results and scalar logic only), so
-    // that the bookkeeping of a reset costs no vector instruction; `inverse_ballot` turns it back into a lane predicate
+    // that the bookkeeping of a reset costs no vector instruction; `inverse_ballot` turns it back into a lane predicate.
+    // Env::kSpareFlagInVgpr (InvPend: its float64 literals fill the scalar file, hipcc kept the mask in two lanes of a
+    // spill register — 2 v_readlane + 2 v_writelane + 2 v_readlane per resetting step, and some lane resets in 95 % of
+    // config 3's wave-steps): a per-lane flag instead, 3 (>= every done code) where the lane holds a spare, else 0 — the
+    // "a resetting lane has no spare" test is then ONE comparison, done > flag, and taking the spare one v_mov
+    constexpr bool kVFlag = Env::kSpareFlagInVgpr;
     unsigned long long spare_mask = 0ull;
+    uint32_t spare_flag = 0u;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         EMEI_STAT_WAVE(16);  // staged-kernel event counters of a -DEMEI_NEWTON_STATS build (tools/pend_stats.py): env-steps (waves)
         const unsigned long long done_mask = __ballot(done != 0) & reset_mask;
         // cold: laid out of line so that the usual case falls through
         if (__builtin_expect(done_mask != 0ull, 0)) {  // scalar test: no vector instruction
             EMEI_STAT_WAVE(17);  // ... steps in which some lane resets
-            if ((done_mask & ~spare_mask) != 0ull) {  // a resetting lane has no spare: redraw for every lane without one
+            const bool refill = kVFlag ? (__ballot(done > spare_flag) & reset_mask) != 0ull : (done_mask & ~spare_mask) != 0ull;
+            if (refill) {  // a resetting lane has no spare: redraw for every lane without one
                 EMEI_STAT_WAVE(18);  // ... spare refills
-                if (__builtin_amdgcn_inverse_ballot_w64(~spare_mask)) {
+                if (kVFlag ? spare_flag == 0u : __builtin_amdgcn_inverse_ballot_w64(~spare_mask)) {
                     typename Env::Carry sc;
                     sc.trig = c.trig;
                     Env::init(sp, a.seed, a.env_offset + (uint64_t)i, episode + 1u, a.p);
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                         Env::save_extra(sc, sp_e0, sp_e1);
                     }
                 }
-                spare_mask = ~0ull;
+                spare_mask = ~0ull, spare_flag = 3u;
             }
             if (__builtin_amdgcn_inverse_ballot_w64(done_mask)) {
                 ++episode;
@@ -278,6 +285,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                     c.sn = sp_sn, c.cs = sp_cs;
                     Env::load_extra(c, sp_e0, sp_e1);
                 }
+                spare_flag = 0u;
             }
             spare_mask &= ~done_mask;
         }
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(kBlock)
                                 typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, trig, Env::trig_scale());
+    stage_trig_table(trig_s, trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     T v[4];
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(kBlock)
                          int freq_rate, typename Env::Params p, const SinCosEntry* trig) {
     using R = typename Env::real;
     __shared__ SinCosEntry trig_s[kTrigTableSize];
-    stage_trig_table(trig_s, trig, Env::trig_scale());
+    stage_trig_table(trig_s, trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     T v[4];

@@ -152,7 +152,7 @@ def test_no_instruction_touches_an_lds_read_destination_before_its_wait(function
 # `s_or_b64 exec, exec, s[..]` that restores EXEC: tools/isa_scan.py (shared with tools/build_variant.sh, which audits every
 # variant build the same way — round 2 took its Hopper RK4 solver statistics from a variant that this bug had broken).
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from isa_scan import exec_restore_hazards  # noqa: E402
+from isa_scan import exec_restore_hazards, lds_inflight_hazards  # noqa: E402
 
 
 # Joins that re-store a spill slot which ALSO has an unmasked store elsewhere are downgraded to notes by the scanner (hipcc
@@ -225,6 +225,47 @@ def test_scanner_flags_both_observed_shapes_and_not_a_plain_then_block():
         0x20 s_or_b64 exec, exec, s[2:3]
     """)
     assert exec_restore_hazards(plain) == []
+
+
+def test_no_lds_read_is_touched_in_flight(functions):
+    """Every kernel of the shipped library: the destination registers of a ds_read are neither written nor read before a
+    wait that retires the read.  hipcc guarantees it for its own loads; the asm LDS read of emei_device.h:sincos_begin_ctx
+    is invisible to it (round 4: the cold large-angle branch was handed the in-flight read's registers as scratch)."""
+    bad = {name: h[:3] for name, ins in functions.items() if (h := lds_inflight_hazards(ins))}
+    assert not bad, bad
+
+
+def test_lds_scanner_flags_the_round4_shape_and_not_its_fix():
+    """Cut down from the CartPole step kernel of the broken build: the table read of the substep is issued, the cold branch
+    is taken, and the angle reduction's first instruction writes v[14:15] while the read into v[14:17] is still out."""
+    broken = _listing("""
+        0x100 ds_read_b128 v[14:17], v14
+        0x108 v_fma_f64 v[90:91], v[88:89], s[44:45], v[32:33]
+        0x110 s_cbranch_vccnz 20
+        0x114 v_mul_f64 v[94:95], v[86:87], v[88:89]
+        0x11c s_waitcnt lgkmcnt(0)
+        0x120 v_mul_f64 v[54:55], v[86:87], v[16:17]
+        0x128 s_endpgm
+        0x164 v_trig_preop_f64 v[14:15], |v[2:3]|, 0
+        0x16c s_waitcnt lgkmcnt(0)
+        0x170 s_branch -21
+    """)
+    h = lds_inflight_hazards(broken)
+    assert len(h) == 1 and h[0][1] == "0x164" and h[0][3] == "write"
+    fixed = [(a, "s_waitcnt", "lgkmcnt(0)") if a == 0x164 else (a, m, o) for a, m, o in broken]
+    assert lds_inflight_hazards(fixed) == []
+    # a younger LDS operation lets lgkmcnt(1) retire the older read (LDS returns in order); a scalar load in between does not
+    inorder = _listing("""
+        0x10 ds_read_b128 v[4:7], v0
+        0x18 ds_read_b32 v8, v1
+        0x20 s_waitcnt lgkmcnt(1)
+        0x24 v_add_f64 v[4:5], v[4:5], v[6:7]
+        0x2c s_waitcnt lgkmcnt(0)
+        0x30 s_endpgm
+    """)
+    assert lds_inflight_hazards(inorder) == []
+    with_smem = inorder[:1] + [(0x14, "s_load_dwordx2", "s[0:1], s[2:3], 0x0")] + inorder[1:]
+    assert [x[1] for x in lds_inflight_hazards(with_smem)] == ["0x24"]
 
 
 def test_every_kernel_fits_the_cu(tmp_path):

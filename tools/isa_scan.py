@@ -10,6 +10,9 @@ Two shapes have been seen:
   (b) round 3, the -DEMEI_NEWTON_STATS Hopper RK4 (the statistics build: every lane but one per wave went non-finite):
       s_and_saveexec sX ; s_cbranch_execz JOIN ; <then block: global_atomic_add> ; JOIN: <spill stores> ; s_or_b64 exec, exec, sX
 
+Round 4 added a second scan, lds_inflight_hazards: the destination of an LDS read touched before the read has retired
+(an asm LDS read is invisible to hipcc's register allocator and wait-count insertion).
+
 Usage: tools/isa_scan.py <library.so> [name filter]      exit status 1 if any kernel is flagged.
 tests/test_isa_guards.py runs the same functions over the shipped library; tools/build_variant.sh over every variant build.
 """
@@ -118,6 +121,78 @@ def exec_restore_hazards(ins, warnings=None):
     return out
 
 
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_NO_VGPR_DEST = ("global_store", "scratch_store", "buffer_store", "flat_store", "ds_write", "ds_add", "ds_max", "ds_min", "v_cmp", "v_nop",
+                 "v_readlane", "v_readfirstlane", "global_atomic", "ds_swizzle_nop", "v_cmpx")
+
+
+def _vregs(text):
+    out = set()
+    for g in _VREG.finditer(text):
+        if g.group(1) is not None:
+            out.add(int(g.group(1)))
+        else:
+            out.update(range(int(g.group(2)), int(g.group(3)) + 1))
+    return out
+
+
+def _dest_and_sources(m, o):
+    """(VGPRs an instruction writes, VGPRs it reads) — good enough for the LDS-in-flight scan below: the first operand is
+    the destination unless the mnemonic stores / compares / reads a lane into a scalar; LDS-DMA loads have no VGPR destination."""
+    if not m.startswith(VECTOR):
+        return set(), set()
+    ops = [x.strip() for x in o.split(",")]
+    if m.startswith(_NO_VGPR_DEST) or "_lds_" in m:
+        return set(), _vregs(o)
+    return _vregs(ops[0]) if ops else set(), _vregs(", ".join(ops[1:]))
+
+
+def lds_inflight_hazards(ins, max_walk=400):
+    """[(addr of the LDS read, addr of the offender, mnemonic, 'write' | 'read')]: an instruction that touches the destination
+    registers of a ds_read before a wait that is guaranteed to have retired it.
+
+    hipcc keeps this invariant for its own LDS loads.  An `asm volatile("ds_read_b128 ...")` (emei_device.h:
+    sincos_begin_ctx) is invisible to it: it takes the output for available at once and, when the value is dead on some
+    path, for free — round 4: the cold large-angle branch got the in-flight read's registers as scratch, and the LDS then
+    delivered into the middle of the angle reduction (CartPole rewards wrong by O(1), differently from run to run).
+    A wait `lgkmcnt(N)` retires the read when N <= the number of LDS operations issued after it (LDS returns in order);
+    scalar loads share the counter and return out of order, so a path with one in between only counts lgkmcnt(0)."""
+    index = {a: k for k, (a, _, _) in enumerate(ins)}
+    out = []
+    for k, (a, m, o) in enumerate(ins):
+        if not m.startswith("ds_read"):
+            continue
+        dest = _vregs(o.split(",")[0])
+        stack, seen = [(k + 1, 0, False, 0)], set()
+        while stack:
+            j, younger, smem, walked = stack.pop()
+            while j < len(ins) and walked < max_walk and j not in seen:
+                seen.add(j)
+                aj, mj, oj = ins[j]
+                if mj == "s_waitcnt":
+                    g = re.search(r"lgkmcnt\((\d+)\)", oj)
+                    if g and (int(g.group(1)) == 0 or (not smem and int(g.group(1)) <= younger)):
+                        break
+                w, r = _dest_and_sources(mj, oj)
+                if w & dest or r & dest:
+                    out.append((hex(a), hex(aj), mj, "write" if w & dest else "read"))
+                    break
+                if mj.startswith("ds_"):
+                    younger += 1
+                if mj.startswith(("s_load", "s_buffer_load")):
+                    smem = True
+                if mj in ("s_endpgm", "s_setpc_b64"):
+                    break
+                t = branch_target(aj, mj, oj)
+                if t is not None and t in index:
+                    stack.append((index[t], younger, smem, walked))
+                    if mj == "s_branch":
+                        break
+                j += 1
+                walked += 1
+    return out
+
+
 def scan_library(lib, name_filter=""):
     """-> (functions scanned, {name: hazards}, {name: re-store sites that are not failures})"""
     with tempfile.TemporaryDirectory() as d:
@@ -127,6 +202,7 @@ def scan_library(lib, name_filter=""):
         if name_filter in name:
             w = []
             h = exec_restore_hazards(ins, w)
+            h += [(rd, [(at, mn, kind + " of the destination of an LDS read still in flight")]) for rd, at, mn, kind in lds_inflight_hazards(ins)]
             if h:
                 bad[name] = h
             if w:
@@ -137,9 +213,9 @@ def scan_library(lib, name_filter=""):
 if __name__ == "__main__":
     n, bad, warn = scan_library(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
     for name, h in bad.items():
-        print(f"HAZARD {name}: {len(h)} exec restore(s) with EXEC-masked instructions in front")
+        print(f"HAZARD {name}: {len(h)} site(s): EXEC-masked instructions in front of an exec restore / LDS reads touched in flight")
         for addr, vec in h[:3]:
-            print(f"   restore at {addr}: " + "; ".join(f"{x[0]} {x[1]} {x[2]}" for x in vec[:6]))
+            print(f"   at {addr}: " + "; ".join(f"{x[0]} {x[1]} {x[2]}" for x in vec[:6]))
     for name, w in warn.items():
         print(f"note {name}: {len(w)} join(s) re-store a slot that also has an unmasked store ({w[0][0]}: {len(w[0][1])} stores)")
     print(f"{sys.argv[1]}: {n} functions scanned, {len(bad)} flagged, {len(warn)} with re-store notes")
