@@ -410,9 +410,15 @@ struct u32x4 {
     uint32_t v[4];
 };
 
+// KEYS_IN_PLACE (the seed must be wave-uniform, e.g. a kernel argument): the key schedule is bumped by scalar additions the
+// compiler cannot hoist.  Left to itself hipcc precomputes the 20 round keys once per kernel; in a kernel whose scalar
+// registers are full (the float64 InvertedPendulum) they live in the lanes of a spill register and every redraw of spare
+// initial states reads them back with 20 v_readlane_b32.
+template <bool KEYS_IN_PLACE = false>
 __device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t env, uint32_t episode, uint32_t block) {
     uint32_t c0 = (uint32_t)env, c1 = (uint32_t)(env >> 32), c2 = episode, c3 = block;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (KEYS_IN_PLACE) k0 = __builtin_amdgcn_readfirstlane(k0), k1 = __builtin_amdgcn_readfirstlane(k1);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one full 32x32->64 product per multiplier (v_mad_u64_u32) instead of mul_hi + mul_lo
@@ -420,8 +426,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t env, uint
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c0 = n0, c1 = (uint32_t)p1, c2 = n2, c3 = (uint32_t)p0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+        if (KEYS_IN_PLACE) {
+            asm("s_add_u32 %0, %0, 0x9E3779B9\n\ts_add_u32 %1, %1, 0xBB67AE85" : "+s"(k0), "+s"(k1) : : "scc");
+        } else {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
     }
     return u32x4{{c0, c1, c2, c3}};
 }

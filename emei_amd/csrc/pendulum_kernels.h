@@ -252,11 +252,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     auto maybe_reset = [&]() __attribute__((always_inline)) {
         EMEI_STAT_WAVE(16);  // staged-kernel event counters of a -DEMEI_NEWTON_STATS build (tools/pend_stats.py): env-steps (waves)
         const unsigned long long done_mask = __ballot(done != 0) & reset_mask;
-        // cold: laid out of line so that the usual case falls through
-        if (__builtin_expect(done_mask != 0ull, 0)) {  // scalar test: no vector instruction
+        // cold for most envs: laid out of line so that the usual case falls through (Env::kResetLikely: in line)
+        if (__builtin_expect(done_mask != 0ull, Env::kResetLikely ? 1 : 0)) {  // scalar test: no vector instruction
             EMEI_STAT_WAVE(17);  // ... steps in which some lane resets
             const bool refill = kVFlag ? (__ballot(done > spare_flag) & reset_mask) != 0ull : (done_mask & ~spare_mask) != 0ull;
-            if (refill) {  // a resetting lane has no spare: redraw for every lane without one
+            if (__builtin_expect(refill, 0)) {  // a resetting lane has no spare: redraw for every lane without one
                 EMEI_STAT_WAVE(18);  // ... spare refills
                 if (kVFlag ? spare_flag == 0u : __builtin_amdgcn_inverse_ballot_w64(~spare_mask)) {
                     typename Env::Carry sc;
