@@ -118,43 +118,54 @@ struct DPendBody {
         R f2 = (R)m.gx * S2z + (R)m.gz * S2x + w1s * fma_r(Dx, S2z, -(Dz * S2x));  // D . perp(S2)
         // symmetric 3x3 [[a b c],[b d e],[c e f]] in the order (x, phi1, phi2): LDL^T eliminating phi2, phi1, x
         const R a = (R)m.mtot, b = S1z, c = S2z, d = (R)m.diag1, e = M12, f = (R)m.diag2;
-        const R if_ = rcp_r(f);
+        // (one Newton step on the hardware reciprocal, <= 2.2e-15 relative: emei_device.h:rcp1_r — as the InvertedPendulum)
+        const R if_ = rcp1_r(f);
         const R le = e * if_, lc = c * if_;          // column of phi2
         const R d1 = fma_r(-le, e, d), b1 = fma_r(-le, c, b), a1 = fma_r(-lc, c, a);
-        const R id1 = rcp_r(d1);
+        const R id1 = rcp1_r(d1);
         const R lb = b1 * id1;
         const R a2 = fma_r(-lb, b1, a1);
-        const R ia2 = rcp_r(a2);
-        // solve M acc = rhs for rhs = (fx, f1, f2) and, when the limit is active, rhs = e_x
-        auto solve = [&](R rx, R r1, R r2, R& ox, R& o1, R& o2) __attribute__((always_inline)) {
-            R y1 = fma_r(-le, r2, r1);                  // forward: phi2 -> phi1, x
-            R yx = fma_r(-lc, r2, rx);
-            yx = fma_r(-lb, y1, yx);
-            ox = yx * ia2;                              // back substitution
-            o1 = fma_r(-lb, ox, y1 * id1);
-            o2 = fma_r(-le, o1, fma_r(-lc, ox, r2 * if_));
-        };
+        const R ia2 = rcp1_r(a2);
+        // solve M acc = rhs for rhs = (fx, f1, f2)
         R ax, a1_, a2_;
-        solve(fx, f1, f2, ax, a1_, a2_);
+        {
+            const R y1 = fma_r(-le, f2, f1);                  // forward: phi2 -> phi1, x
+            const R yx = fma_r(-lb, y1, fma_r(-lc, f2, fx));
+            ax = yx * ia2;                                    // back substitution
+            a1_ = fma_r(-lb, ax, y1 * id1);
+            a2_ = fma_r(-le, a1_, fma_r(-lc, ax, f2 * if_));
+        }
         // soft slider limit with margin 0.01 (mjCNSTR_LIMIT_JOINT: active when dist < margin)
-        // x_lo + margin < x_hi - margin: at most one side is active, the smaller distance is it
-        const R dlo = q[0] - (R)m.x_lo, dhi = (R)m.x_hi - q[0];
-        const bool lower = dlo < dhi;
-        const R dist = lower ? dlo : dhi, J = lower ? R(1) : R(-1);
-        if (dist < (R)m.margin) {
-            R wx, w1_, w2_;
-            solve(R(1), R(0), R(0), wx, w1_, w2_);
-            const R pos = dist - (R)m.margin;
-            const R xx = div_r(fabs(pos), (R)m.width);
-            const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : R(1) - R(2) * (R(1) - xx) * (R(1) - xx));
-            const R imp = (R)m.dmin + y * ((R)m.dmax - (R)m.dmin);
-            const R aref = -(R)m.B * (J * v[0]) - (R)m.K * imp * pos;
-            const R Rr = div_r(R(1) - imp, imp) * (R)m.invw;
-            const R force = div_r(aref - J * ax, wx + Rr);
-            if (force > R(0)) {
-                ax = fma_r(wx, J * force, ax);
-                a1_ = fma_r(w1_, J * force, a1_);
-                a2_ = fma_r(w2_, J * force, a2_);
+        // x_lo + margin < x_hi - margin: at most one side is active, the smaller distance is it.  The rail is symmetric, so
+        // dist = x_hi - |x| and J = -sign(x).  Some lane of a wave is at the rail in about half of the evaluations (random
+        // pushes), a few per cent of the lanes: the block is written as the InvertedPendulum's (pendulum_envs.h:slider_row) —
+        // M^-1 e_x = (1, -lb, lb le - lc) / a2 from the factor instead of a second substitution, J as a +-1.0 factor of an
+        // fma, -K imp pos = fma(K imp, |x|, -K imp (x_hi - margin)), the impedance polynomial and the division by imp only in
+        // waves with a lane inside the 1 mm width, the force clamped by a maximum.
+        static_assert(dpend::kXml.x_lo == -dpend::kXml.x_hi, "symmetric slider range");
+        const R ax_abs = abs_r(q[0]);
+        if (ax_abs > (R)(m.x_hi - m.margin)) {
+            const R nJ = copysign_r(R(1), q[0]);                  // -J
+            const R n1 = fma_r((R)m.B, v[0], ax);                 // aref - J ax = nJ (B v + ax) - K imp pos
+            const R wx = ia2, w1_ = -lb * ia2, w2_ = fma_r(lb, le, -lc) * ia2;
+            auto finish = [&](R Kimp, R Kimp_edge, R Rr) __attribute__((always_inline)) {
+                const R num = fma_r(nJ, n1, fma_r(Kimp, ax_abs, -Kimp_edge));
+                const R g = nJ * fmax_r(num * rcp1_r(wx + Rr), R(0));  // -J force
+                ax = fma_r(-wx, g, ax);
+                a1_ = fma_r(-w1_, g, a1_);
+                a2_ = fma_r(-w2_, g, a2_);
+            };
+            const R edge = (R)(m.x_hi - m.margin);
+            const R Kfull = (R)m.K * (R)m.dmax;
+            const bool full = !(ax_abs < (R)(m.x_hi - m.margin + m.width));
+            if (__builtin_expect(__ballot(!full) != 0ull, 0)) {
+                const R xx = (ax_abs - edge) * (R)(1.0 / m.width), u1 = R(1) - xx;
+                const R y = xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1));
+                const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+                const R Kimp = full ? Kfull : (R)m.K * imp;
+                finish(Kimp, Kimp * edge, full ? (R)((1.0 - m.dmax) / m.dmax) * (R)m.invw : (R(1) - imp) * (R)m.invw * rcp1_r(imp));
+            } else {
+                finish(Kfull, Kfull * edge, (R)((1.0 - m.dmax) / m.dmax) * (R)m.invw);
             }
         }
         qacc[0] = ax, qacc[1] = a1_, qacc[2] = a2_ - a1_;  // theta2'' = Omega2' - Omega1'
