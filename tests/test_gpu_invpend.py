@@ -139,6 +139,44 @@ def test_device_reset_matches_oracle_spec():
     assert np.abs(got - want).max() <= 1e-8
 
 
+@pytest.mark.parametrize("variant", ["boundary_swingup", "boundary_balancing"])
+def test_autoreset_rollout_vs_oracle(variant):
+    """Device-side resets of the staged kernel (spare initial states, the per-lane spare flag, TimeLimit) against the oracle
+    stepped and reset the same way, over several episodes per env: done codes bit for bit (which step ends an episode, and
+    why), observations / rewards to float32 tolerance.  The twin restarts an env from the oracle's exact Box-Muller draw of
+    (seed, env, episode); the device's hardware transcendentals differ from it by <= 1e-8 (test_device_reset_matches_oracle_spec),
+    which a 30-step episode amplifies to ~1e-6."""
+    from oracle import oracle as O
+
+    N, T, seed, off, max_steps, fr, sigma = 256, 96, 9, 4000, 30, 4, 5e-3
+    eng = _engine(VARIANTS[variant], N, freq_rate=fr, init_noise=sigma, max_episode_steps=max_steps, seed=seed, env_index_offset=off)
+    eng.reset(seed)
+    st = eng.get_state().cpu().numpy()
+    acts = np.random.default_rng(13).uniform(-3, 3, (T, N)).astype(np.float32)  # +-300 N: the cart leaves the rail within ~20 steps
+    obs, rew, done = eng.rollout(torch.as_tensor(acts, device=eng.device), auto_reset=True)
+    from emei_amd import _lib as L
+
+    assert eng.last_kernel() == L.KERNEL_PEND_STAGED
+    steps, epi = np.zeros(N, np.int64), np.zeros(N, np.int64)
+    o_obs, o_rew, o_done = np.empty((T, N, 4)), np.empty((T, N)), np.zeros((T, N), np.uint8)
+    for t in range(T):
+        st, o_obs[t], o_rew[t], term = O.ip_step(variant, st, acts[t].astype(np.float64), fr, 0.02)
+        steps += 1
+        o_done[t] = term.astype(np.uint8) | ((steps >= max_steps).astype(np.uint8) << 1)
+        for i in np.nonzero(o_done[t])[0]:
+            epi[i] += 1
+            steps[i] = 0
+            st[i] = O.ip_init_f32(seed, off + i, epi[i], sigma).astype(np.float64)
+    assert np.array_equal(done.cpu().numpy(), o_done)
+    # both kinds of ending (a balancing pole under these pushes never lasts 30 steps); every env restarted at least twice
+    assert (o_done & 1).any() and ((o_done & 2).any() or variant == "boundary_balancing") and epi.min() >= 2
+    # an ABSOLUTE error set by O(1)-O(10) dynamics (floor 1.0): positions and angles pass through zero
+    assert rel_err(obs.cpu().numpy(), o_obs, floor=1.0) <= 2e-5
+    assert rel_err(rew.cpu().numpy(), o_rew, floor=1.0) <= 2e-5
+    _, e = eng.get_counters()
+    assert np.array_equal(e.cpu().numpy(), epi)
+
+
 def test_full_size_config3_properties():
     """BASELINE configs[2]: 262 144 envs, freq_ratio 4 — rollout == chunked rollouts; obs angle in [-pi, pi)."""
     N, T = 262144, 32
