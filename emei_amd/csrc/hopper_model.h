@@ -644,19 +644,33 @@ __device__ __forceinline__ void accel_newton(const R (&q)[NV], const R (&v)[NV],
     EMEI_STAT_LANE(0);
     EMEI_STAT_WAVE(7);
     EMEI_MARK(nw_smooth0);
-    // qacc_smooth = M^-1 qfrc_smooth for every lane (cheetah_model.h): free flight without implicit damping, the cold start
-    build_inertia(A, R(0));
-    ldl_factor(A, invd);
+    // qacc_smooth = M^-1 qfrc_smooth (cheetah_model.h): free flight without implicit damping, and the cold start of the
+    // iteration.  Only COLD evaluations need it — the first of an env-step; the other 15 of an RK4 step start from the previous
+    // minimiser in every lane of the wave (body_kernels.h: `warm` lives for one env-step), and a free-flight lane then takes the
+    // loop below with no row: its first step from the previous minimiser is a - M^-1 (M a - f) = M^-1 f, which the verify
+    // sweep confirms (no row before, no row after) inside passes the wave runs for its other lanes anyway.  Wave-uniform
+    // skip of ~150 instructions in 15 of 16 evaluations.
+    const bool cold = !warm.valid;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = f[i];
-    ldl_forward<0>(A, a);
+    for (int i = 0; i < NV; ++i) a[i] = R(0);
+    if (__ballot(cold) != 0ull) {
+        build_inertia(A, R(0));
+        ldl_factor(A, invd);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] *= invd[i];
-    ldl_backward(A, a);
-    if (rows == 0u) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
+        for (int i = 0; i < NV; ++i) a[i] = f[i];
+        ldl_forward<0>(A, a);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] *= invd[i];
+        ldl_backward(A, a);
+    }
+    if (rows == 0u && cold) {  // free flight: qacc = (M + h B)^-1 qfrc_smooth
         if (hd > R(0)) {  // Euler: solved with the constrained lanes' damping step at the end (cheetah_model.h)
 #pragma unroll
             for (int i = 0; i < NV; ++i) a[i] = R(0);
+        } else {  // the next stage evaluations start from it (or the lane would stay cold for as long as it is airborne)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) warm.a[i] = a[i];
+            warm.valid = true;
         }
     } else {
         EMEI_STAT_LANE(1);
