@@ -161,6 +161,8 @@ from isa_scan import exec_restore_hazards, lds_inflight_hazards  # noqa: E402
 # the test until its disassembly has been read.
 #   HopperBody<float, 0>, RK4: 12 stores to consecutive AGPRs at the tail of the auto-reset then-block, writing the NEW state
 #   under the done mask in front of the restore; the reload reads what the unmasked path stored for the other lanes.  Legitimate.
+#   (The site went away with a later round-4 change of the Hopper solve; the entry stays: a note there is reviewed, a note
+#   anywhere else is not.)
 REVIEWED_RESTORE_NOTES = {"body_rollout_kernelINS_10HopperBodyIfLi0EEELb1EEE": 1}
 
 
