@@ -17,6 +17,7 @@
 //   kHasCtrlCost, ctrl_cost(act)                    // the reward has a control-cost term w_ctrl * sum a^2 (whole-batch quirk mode)
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
+//   park(s)                                         // state of the padding lanes of a ragged last wave
 //   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
 //   kUnrollRK4                                      // RK4 stages as straight-line code (see body_substep)
 //   kScratchPerLane                                 // elements of `real` of block LDS per lane that accel() may use (0: none)
@@ -270,8 +271,14 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
         steps = a.steps[i];
         episode = a.episode[i];
     } else {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = R(0);
+        // Padding lanes of a ragged last wave run the arithmetic of their wave (its branches are wave-uniform) on a state of their
+        // own, and the cheetah's three-block lanes borrow a constraint slot from a wave-mate with at most one row block
+        // (cheetah_model.h: `donor`).  From the zero state a padding cheetah stands on both feet — two blocks, no slot to lend —
+        // and it fell differently in a fused rollout than in the same rollout cut into chunks (every launch parks it anew):
+        // whether the one real env of an n = 1 engine found a donor, and so which of two solvers it ran, depended on the
+        // chunking (tools/stress.py, round 4; the two agree to ~1e-13, not bit for bit).  Parked in the air a padding lane has
+        // no row, ever.
+        Body::park(s);
     }
     const bool auto_reset = (a.flags & EMEI_FLAG_AUTO_RESET) != 0;
     const bool obs_noise = a.noise.obs_on != 0;

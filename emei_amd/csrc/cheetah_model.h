@@ -1366,6 +1366,13 @@ struct CheetahBody {
         term = !fin;
     }
     __device__ __forceinline__ static void init_base(R (&)[NS]) {}  // init_qpos = init_qvel = 0
+    // the state of the padding lanes of a ragged last wave (body_kernels.h): far above the floor, at rest — no row ever, the
+    // cheapest path through accel(), and a lane that never needs its second constraint slot
+    __device__ __forceinline__ static void park(R (&s)[NS]) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = R(0);
+        s[1] = R(1e6);
+    }
     __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) o[k] = (double)s[k];

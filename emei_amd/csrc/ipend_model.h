@@ -134,6 +134,11 @@ struct InvPendBody {
         for (int k = 0; k < NO; ++k) o[k] = (float)ob[k];
     }
     __device__ __forceinline__ static void init_base(R (&)[NS]) {}  // init_qpos = init_qvel = 0
+    // the state of the padding lanes of a ragged last wave (body_kernels.h): at rest in the middle of the rail
+    __device__ __forceinline__ static void park(R (&s)[NS]) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = R(0);
+    }
     __device__ __forceinline__ static void obs_of(const R (&s)[NS], double (&o)[NO], const Model&) {
         o[0] = (double)s[0], o[1] = (double)wrap(s[1]), o[2] = (double)s[2], o[3] = (double)s[3];
     }
