@@ -362,6 +362,13 @@ def main():
                                 "measured_ns_per_f64_inst": MEASURED_NS_PER_F64_INST,
                                 "frac_at_measured_rate": valu * MEASURED_NS_PER_F64_INST / (SIMDS * kernel_ms * 1e6),
                                 "source": f"{prof.get('profile', 'profiles/')} SQ pass via profiles/traffic.json, NOT measured in this run"}
+        # `frac_at_probed_clock`: the same count at the shader clock the kernel's waves were MEASURED to run at (tools/clock_probe.py,
+        # profiles/r04_clock_probe.txt: s_memtime against the 100 MHz s_memrealtime over every wave's lifetime).  The float64-dense
+        # four-waves-per-SIMD kernels are power-limited far below 2.4 GHz (config 3: 1.65 GHz, and 100 % of one instruction per four
+        # cycles at that clock); the one-wave-per-SIMD bodies run at 2.38 GHz.
+        if prof.get("shader_clock_ghz"):
+            out["roofline_valu"]["probed_clock_ghz"] = prof["shader_clock_ghz"]
+            out["roofline_valu"]["frac_at_probed_clock"] = valu * 4 / (SIMDS * prof["shader_clock_ghz"] * 1e9 * kernel_ms * 1e-3)
     # what actually ran: the ranks the process group formed, its backend, every rank's device
     me = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
     devices = [me]

@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     trig.scratch_stride = kBlock;
     trig.cap_hits = a.cap_hits;
     EMEI_PROFILE_BEGIN();
+    EMEI_CLOCK_BEGIN();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t n = a.n;
@@ -401,6 +402,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     }
     unsigned long long mk = __ballot(done != 0);
     if (lane == 0 && active) a.done_mask[i / kWave] = mk;
+    EMEI_CLOCK_END();
     EMEI_PROFILE_END();
 }
 

@@ -38,7 +38,7 @@ extern "C" __attribute__((visibility("default"))) int EMEI_CATP(emei_cycle_stats
 }
 #endif
 
-#ifdef EMEI_NEWTON_STATS
+#if defined(EMEI_NEWTON_STATS) || defined(EMEI_CLOCK_PROBE)
 // variant builds only (tools/newton_stats.py): copy out and clear this translation unit's solver counters
 #define EMEI_CAT2(a, b) a##b
 #define EMEI_CAT(a, b) EMEI_CAT2(a, b)

@@ -21,6 +21,29 @@ constexpr int kWave = 64;
 // staged pendulum kernels (pendulum_kernels.h, pendulum_envs.h):
 //   16 env-steps (waves)   17 ... in which some lane resets   18 ... in which spares are redrawn
 //   19 substeps (waves)   20 ... that run the slider-limit block   21 lanes beyond the rail
+// -DEMEI_CLOCK_PROBE (tools/clock_probe.py, round 4; a variant build, nothing else changes): every wave of a rollout kernel
+// reads the shader clock (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts and when it ends;
+// slots 28 / 29 / 30 = sum of shader cycles, sum of 100 MHz ticks, waves.  Their ratio is the clock the kernel really ran at.
+#if defined(EMEI_CLOCK_PROBE) && !defined(EMEI_NEWTON_STATS)
+static __device__ unsigned long long g_debug_stats[32];
+#endif
+#ifdef EMEI_CLOCK_PROBE
+struct ClockProbe {
+    unsigned long long c0, r0;
+    __device__ __forceinline__ void begin() { c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void end() const {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {
+            atomicAdd(&g_debug_stats[28], c1 - c0), atomicAdd(&g_debug_stats[29], r1 - r0), atomicAdd(&g_debug_stats[30], 1ull);
+        }
+    }
+};
+#define EMEI_CLOCK_BEGIN() emei::ClockProbe clock_probe_; clock_probe_.begin()
+#define EMEI_CLOCK_END() clock_probe_.end()
+#else
+#define EMEI_CLOCK_BEGIN() ((void)0)
+#define EMEI_CLOCK_END() ((void)0)
+#endif
 #ifdef EMEI_NEWTON_STATS
 static __device__ unsigned long long g_debug_stats[32];
 // Branch-free on purpose: one atomic per ACTIVE lane with an addend of 1 (LANE) or of 1 for the first active lane and 0 for the

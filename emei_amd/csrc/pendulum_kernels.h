@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
     if (i >= a.n) return;
+    EMEI_CLOCK_BEGIN();
     const int64_t n = a.n;
     const uint32_t li = (uint32_t)i, i0 = li - (uint32_t)lane;
     const ActT* __restrict__ actions = (const ActT*)a.actions;
@@ -379,6 +380,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     a.episode[i] = episode;
     unsigned long long m = __ballot(done != 0);
     if (lane == 0) a.done_mask[i / kWave] = m;
+    EMEI_CLOCK_END();
 #undef EMEI_LOAD_TILE
 }
 

@@ -7,8 +7,8 @@ namespace emei {
 int EMEI_TU_NAME(const PendLaunch& L) { return launch_env<EMEI_TU_FAMILY<EMEI_TU_VARIANT, EMEI_TU_REAL>>(L); }
 }  // namespace emei
 
-#ifdef EMEI_NEWTON_STATS
-// variant builds only (tools/pend_stats.py): copy out and clear this translation unit's event counters (emei_device.h)
+#if defined(EMEI_NEWTON_STATS) || defined(EMEI_CLOCK_PROBE)
+// variant builds only (tools/pend_stats.py, tools/clock_probe.py): copy out and clear this translation unit's event counters (emei_device.h)
 #define EMEI_CAT2(a, b) a##b
 #define EMEI_CAT(a, b) EMEI_CAT2(a, b)
 extern "C" __attribute__((visibility("default"))) int EMEI_CAT(emei_debug_stats_, EMEI_TU_NAME)(unsigned long long* out) {
