@@ -421,10 +421,38 @@ __device__ __forceinline__ T pymod_pos(T a, T p, T inv_p) {
     return w;
 }
 
+// pymod_pos(theta + pi, 2 pi) - pi, the angle wrap of the observations (inverted_pendulum.py:45-49), with the one-period fix-up
+// behind ONE wave-uniform test: w in [0, 2 pi) <=> |w - pi| <= pi, so the result of the usual case is tested itself (|o| >= pi:
+// the fix-up, and o = -pi exactly, which the cold path leaves alone) — 6 vector instructions instead of 9 per env-step of the
+// staged InvertedPendulum kernel, the same bits in every case (the cold path is pymod_pos's own sequence).
+template <typename T>
+__device__ __forceinline__ T wrap_pi(T theta, bool& finite) {  // finite: of the result (and so of theta); free in the usual case
+    const T pi = T(3.141592653589793), p = T(2) * pi;
+    const T a = theta + pi;
+    const T k = floor(a * T(1.0 / (2 * 3.141592653589793)));
+    const T w = fma_r(-k, p, a);
+    T o = w - pi;
+    finite = true;
+    if (__builtin_expect(__ballot(!(fabs(o) < pi)) != 0ull, 0)) {  // also entered by NaN lanes, which it leaves as they are
+        T w2 = w;
+        if (w2 < T(0)) w2 += p;
+        else if (w2 >= p) w2 -= p;
+        o = w2 - pi;
+        finite = ::isfinite(o);
+    }
+    return o;
+}
+template <typename T>
+__device__ __forceinline__ T wrap_pi(T theta) {
+    bool f;
+    return wrap_pi(theta, f);
+}
+
 template <typename T>
 __device__ __forceinline__ bool finite_r(T v) {
     return ::isfinite(v);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11): the device-side reset generator.

@@ -391,28 +391,28 @@ struct InvPend {
             const R nJ = copysign_r(R(1), x_old);  // -J
             const R n1 = fma_r((R)p.limB, v_old, a0);  // aref - J a0 = nJ (B v + a0) - K imp dist
             const R A = (R)m.M22 * idet;
-            auto finish = [&](R Kimp, R Kimp_xhi, R Rr) __attribute__((always_inline)) {
-                const R num = fma_r(nJ, n1, fma_r(Kimp, abs_r(x_old), -Kimp_xhi));  // -K imp dist, dist = x_hi - |x|
-                const R force = fmax_r(num * rcp1_r(A + Rr), R(0));
-                const R g = (nJ * force) * idet;  // M^-1 J' force = -(M22, -Q) g
-                a0 = fma_r(-(R)m.M22, g, a0);
-                a1 = fma_r(Q, g, a1);
-            };
-            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost always —
-            // then the wave skips the polynomial).  A lane's bits must not depend on the branch its WAVE took: a lane beyond the
-            // width takes the constants in either branch (`full` is the same predicate as the ballot's).
+            // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost always).
+            // The two terms that depend on it — the position part of aref and the denominator — are formed for the saturated
+            // impedance first, from constants; a wave with a lane inside the width overwrites them for that lane in a cold branch
+            // (as two arms of a branch that share the rest, hipcc routed the constants through v_mov_b64).  A lane's bits do not
+            // depend on the branch its WAVE took: a lane beyond the width keeps the constants' values either way.
             constexpr double kRfull = (1.0 - m.dmax) / m.dmax * m.invw;
             const R Kfull = (R)p.limK * (R)m.dmax, Kfull_xhi = Kfull * (R)m.x_hi;
+            R kpos = fma_r(Kfull, abs_r(x_old), -Kfull_xhi);  // -K imp dist, dist = x_hi - |x|
+            R den = A + (R)kRfull;                              // J M^-1 J' + R
             const bool full = !(abs_r(x_old) < (R)(m.x_hi + m.width));
             if (__builtin_expect(__ballot(!full) != 0ull, 0)) {
                 const R xx = (abs_r(x_old) - (R)m.x_hi) * (R)m.inv_width, u1 = R(1) - xx;
                 const R y = xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1));
                 const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
-                const R Kimp = full ? Kfull : (R)p.limK * imp;
-                finish(Kimp, full ? Kfull_xhi : Kimp * (R)m.x_hi, full ? (R)kRfull : (R(1) - imp) * (R)m.invw * rcp1_r(imp));
-            } else {
-                finish(Kfull, Kfull_xhi, (R)kRfull);
+                const R Kimp = (R)p.limK * imp;
+                kpos = full ? kpos : fma_r(Kimp, abs_r(x_old), -(Kimp * (R)m.x_hi));
+                den = full ? den : A + (R(1) - imp) * (R)m.invw * rcp1_r(imp);
             }
+            const R force = fmax_r(fma_r(nJ, n1, kpos) * rcp1_r(den), R(0));
+            const R g = (nJ * force) * idet;  // M^-1 J' force = -(M22, -Q) g
+            a0 = fma_r(-(R)m.M22, g, a0);
+            a1 = fma_r(Q, g, a1);
         };
         // Balancing variants: the hinge's +-90 degree stop (a post-terminal state).  A wave with such a lane takes a cold,
         // wave-uniform branch in which THAT lane runs the general two-row solve (ip_limit_rows handles its slider row too) and
@@ -436,9 +436,8 @@ struct InvPend {
     }
 
     __device__ __forceinline__ static void obs_of(const R s[4], R o[4]) {
-        const R pi = R(3.141592653589793);
         o[0] = s[0];
-        o[1] = pymod_pos(s[1] + pi, R(2) * pi, R(1.0 / (2 * 3.141592653589793))) - pi;  // inverted_pendulum.py:45-49
+        o[1] = wrap_pi(s[1]);  // inverted_pendulum.py:45-49
         o[2] = s[2], o[3] = s[3];
     }
 
@@ -458,9 +457,13 @@ struct InvPend {
         return VARIANT >= 2 ? (R(1) - cos_theta(c, p)) / R(2) : R(1);
     }
     __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const Params& p) {
+        return terminal(o, c, p, finite_r(o[1]));
+    }
+    // fin1: whether o[1] is finite (step() has it from wrap_pi for nothing in the usual case)
+    __device__ __forceinline__ static bool terminal(const R o[4], const Carry& c, const Params& p, bool fin1) {
         bool inx = ((R)km().x_lo < o[0]) & (o[0] < (R)km().x_hi);
         // np.isfinite(obs).all(); where `inx` is part of the test it already fails for a NaN / infinite x
-        bool fin = finite_r(o[1]) & finite_r(o[2]) & finite_r(o[3]);
+        bool fin = fin1 & finite_r(o[2]) & finite_r(o[3]);
         if (VARIANT == 0 || VARIANT == 2) fin &= finite_r(o[0]);
         R y = cos_theta(c, p);
         bool notdone;
@@ -474,9 +477,10 @@ struct InvPend {
     __device__ __forceinline__ static void step(R s[4], Carry& c, Action gu, const Params& p, int freq_rate,
                                                 R o[4], R& rew, bool& term) {
         for (int k = 0; k < freq_rate; ++k) substep(s, c, gu, p);  // mujoco_env.py:88-97
-        obs_of(s, o);
+        bool fin1;
+        o[0] = s[0], o[1] = wrap_pi(s[1], fin1), o[2] = s[2], o[3] = s[3];  // obs_of
         rew = reward(o, c, p);
-        term = terminal(o, c, p);
+        term = terminal(o, c, p, fin1);
     }
 
     // device reset: init_qpos/qvel (zeros) + sigma * N(0,1) (mujoco_env.py:137-140); same draws as
