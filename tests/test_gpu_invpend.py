@@ -301,3 +301,37 @@ def test_a_lane_at_the_hinge_stop_does_not_change_its_wave_mates(variant):
     for a, b in zip(out[0], out[1]):
         a, b = (a[:, others], b[:, others]) if a.shape[0] == T else (a[others], b[others])
         assert np.array_equal(a, b)
+
+
+def test_angle_wrap_at_its_boundaries():
+    """inverted_pendulum.py:45-49: theta -> (theta + pi) % (2 pi) - pi.  The kernels test the wrapped result once (|o| >= pi) and
+    repair in a cold branch (emei_device.h:wrap_pi); these angles sit on and next to the wrap points, where that branch runs:
+    bit for bit against NumPy's floored modulo, through emei_step (generic kernel), a staged rollout and emei_get_obs."""
+    pi = np.pi
+    base = np.array([0.0, pi, -pi, 3 * pi, -3 * pi, 2 * pi, -2 * pi, 101 * pi, -101 * pi, 600.0, -600.0, 1e5 * pi, -1e5 * pi])
+    theta = np.concatenate([base, np.nextafter(base, np.inf), np.nextafter(base, -np.inf), base + 1e-9, base - 1e-9,
+                            np.random.default_rng(3).uniform(-50, 50, 999)])
+    n = 1024 * ((len(theta) + 1023) // 1024)
+    theta = np.resize(theta, n)
+    want = (theta + pi) % (2 * pi) - pi
+
+    def same(got, ref):
+        # bit for bit — except on the wrap point itself, where NumPy's own remainder can round up to the modulus (theta one ulp
+        # below -pi gives +pi there, -pi here: the same angle, one representative each)
+        at_wrap = (np.abs(np.abs(got.astype(np.float64)) - pi) < 1e-6) & (np.abs(np.abs(ref.astype(np.float64)) - pi) < 1e-6)
+        return bool(np.all((got == ref) | at_wrap))
+
+    s0 = np.zeros((n, 4))
+    s0[:, 1] = theta  # at rest: the position update uses the OLD velocity (mujoco_env.py:189-191), so theta stays put
+    zero = torch.zeros((16, n), dtype=torch.float32, device="cuda")
+    for name in ("BoundaryInvertedPendulumSwingUp", "ReboundInvertedPendulumBalancing"):
+        eng = _engine(name, n, freq_rate=1, real_time_scale=0.02)
+        eng.set_state(s0)
+        assert same(eng.get_obs().cpu().numpy()[:, 1], want)
+        obs, _, _ = eng.step(zero[0])
+        assert np.array_equal(eng.get_state().cpu().numpy()[:, 1], theta)
+        assert same(obs.cpu().numpy()[:, 1], want.astype(np.float32))
+        eng.set_state(s0)
+        obs, _, _ = eng.rollout(zero[:8].contiguous())  # the staged kernel; the first step's angle is still theta
+        assert same(obs[0].cpu().numpy()[:, 1], want.astype(np.float32))
+        eng.close()
