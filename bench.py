@@ -47,6 +47,8 @@ WORKLOADS = {
                                desc="CartPoleBalancing-v0, 65 536 parallel envs"),
     "invpend": dict(env="BoundaryInvertedPendulumSwingUp", n=262144, freq_rate=4, dt=0.02, horizon=250,
                     desc="InvertedPendulum forward-Euler, 262 144 parallel envs, freq_ratio=4 (BASELINE configs[2])"),
+    "invpend_balancing": dict(env="BoundaryInvertedPendulumBalancing", n=262144, freq_rate=4, dt=0.02, horizon=250,
+                              desc="InvertedPendulum Balancing forward-Euler, 262 144 parallel envs, freq_ratio=4 (SURVEY 8d config 3, second variant)"),
     "dpend": dict(env="BoundaryInvertedDoublePendulumSwingUp", n=262144, freq_rate=4, dt=0.02, horizon=100,
                   desc="InvertedDoublePendulum forward-Euler, 262 144 parallel envs, freq_ratio=4 (SURVEY 8f rank 3)"),
     "cheetah": dict(env="HalfCheetahRunning", n=131072, freq_rate=4, dt=0.002, horizon=100,

@@ -377,56 +377,70 @@ struct InvPend {
         static_assert(m.x_lo == -m.x_hi, "symmetric slider range");
         const bool beyond = abs_r(x_old) > (R)m.x_hi;
         EMEI_STAT_WAVE(19);  // substeps (waves)
-        // The slider row alone, in closed form (the hot path's limit block: config 3 runs it in 55 % of a wave's substeps for
-        // 1.7 % of the lanes, so every instruction here is worth half an instruction of the substep itself).
+        // One limit row alone, in closed form (the hot path's limit block: config 3 runs the slider's in 55 % of a wave's substeps
+        // for 1.7 % of the lanes, so every instruction here is worth half an instruction of the substep itself).  For the slider:
         //   J = -sign(x) (+1 at the lower stop), dist = x_hi - |x|, imp = impedance(|dist| / width),
         //   aref = -K imp dist - B J v,  R = (1 - imp) / imp invw,  A = J M^-1 J' = M22 / det
         //   force = max(0, (aref - J a0) / (A + R)),  a += M^-1 J' force
         // written with aref - J a0 = J (-B v - a0) - K imp dist so that J only ever multiplies (a +-1.0 factor of an fma, not
         // sign-bit surgery on copies), with -K imp dist = fma(K imp, |x|, -K imp x_hi) (exact: x_hi - |x| is, by Sterbenz), and
         // with the force clamped by a maximum instead of a branch.
-        auto slider_row = [&]() __attribute__((always_inline)) {
-            EMEI_STAT_WAVE(20);  // ... with the limit block
-            EMEI_STAT_LANE(21);  // lanes beyond the rail
-            const R nJ = copysign_r(R(1), x_old);  // -J
-            const R n1 = fma_r((R)p.limB, v_old, a0);  // aref - J a0 = nJ (B v + a0) - K imp dist
-            const R A = (R)m.M22 * idet;
+        // (one closed form for either joint — DOF 0: the slider's rail, DOF 1: the Balancing variants' +-90 degree hinge stop, whose
+        // range is symmetric as well; M^-1 = idet [[M22, -Q], [-Q, M11]])
+        auto limit_row = [&](auto dof_c) __attribute__((always_inline)) {
+            constexpr int DOF = decltype(dof_c)::value;
+            constexpr double q_hi = DOF == 0 ? m.x_hi : m.th_hi, invw = DOF == 0 ? m.invw : m.invw_hinge, Mdd = DOF == 0 ? m.M22 : m.M11;
+            const R qd = DOF == 0 ? x_old : th_old, vd = DOF == 0 ? v_old : om_old;
+            R& ad = DOF == 0 ? a0 : a1;
+            R& ao = DOF == 0 ? a1 : a0;
+            if (DOF == 0) {
+                EMEI_STAT_WAVE(20);  // ... with the limit block
+                EMEI_STAT_LANE(21);  // lanes beyond the rail
+            }
+            const R nJ = copysign_r(R(1), qd);  // -J
+            const R n1 = fma_r((R)p.limB, vd, ad);  // aref - J a = nJ (B v + a) - K imp dist
+            const R A = (R)Mdd * idet;
             // impedance: xx = |dist| / width; y = 1 beyond the width (1 mm: every violating lane of the wave, almost always).
             // The two terms that depend on it — the position part of aref and the denominator — are formed for the saturated
             // impedance first, from constants; a wave with a lane inside the width overwrites them for that lane in a cold branch
             // (as two arms of a branch that share the rest, hipcc routed the constants through v_mov_b64).  A lane's bits do not
             // depend on the branch its WAVE took: a lane beyond the width keeps the constants' values either way.
-            constexpr double kRfull = (1.0 - m.dmax) / m.dmax * m.invw;
-            const R Kfull = (R)p.limK * (R)m.dmax, Kfull_xhi = Kfull * (R)m.x_hi;
-            R kpos = fma_r(Kfull, abs_r(x_old), -Kfull_xhi);  // -K imp dist, dist = x_hi - |x|
-            R den = A + (R)kRfull;                              // J M^-1 J' + R
-            const bool full = !(abs_r(x_old) < (R)(m.x_hi + m.width));
+            constexpr double kRfull = (1.0 - m.dmax) / m.dmax * invw;
+            const R Kfull = (R)p.limK * (R)m.dmax, Kfull_hi = Kfull * (R)q_hi;
+            R kpos = fma_r(Kfull, abs_r(qd), -Kfull_hi);  // -K imp dist, dist = q_hi - |q|
+            R den = A + (R)kRfull;                         // J M^-1 J' + R
+            const bool full = !(abs_r(qd) < (R)(q_hi + m.width));
             if (__builtin_expect(__ballot(!full) != 0ull, 0)) {
-                const R xx = (abs_r(x_old) - (R)m.x_hi) * (R)m.inv_width, u1 = R(1) - xx;
+                const R xx = (abs_r(qd) - (R)q_hi) * (R)m.inv_width, u1 = R(1) - xx;
                 const R y = xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1));
                 const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
                 const R Kimp = (R)p.limK * imp;
-                kpos = full ? kpos : fma_r(Kimp, abs_r(x_old), -(Kimp * (R)m.x_hi));
-                den = full ? den : A + (R(1) - imp) * (R)m.invw * rcp1_r(imp);
+                kpos = full ? kpos : fma_r(Kimp, abs_r(qd), -(Kimp * (R)q_hi));
+                den = full ? den : A + (R(1) - imp) * (R)invw * rcp1_r(imp);
             }
             const R force = fmax_r(fma_r(nJ, n1, kpos) * rcp1_r(den), R(0));
-            const R g = (nJ * force) * idet;  // M^-1 J' force = -(M22, -Q) g
-            a0 = fma_r(-(R)m.M22, g, a0);
-            a1 = fma_r(Q, g, a1);
+            const R g = (nJ * force) * idet;  // M^-1 J' force = -(Mdd, -Q) g
+            ad = fma_r(-(R)Mdd, g, ad);
+            ao = fma_r(Q, g, ao);
         };
-        // Balancing variants: the hinge's +-90 degree stop (a post-terminal state).  A wave with such a lane takes a cold,
-        // wave-uniform branch in which THAT lane runs the general two-row solve (ip_limit_rows handles its slider row too) and
-        // every other lane the same closed form as on the hot path: a lane's bits never depend on its wave-mates.
+        // Balancing variants: the hinge's +-90 degree stop.  BoundaryBalancing terminates exactly there (cos theta < 0), so with
+        // auto-reset every terminating lane spends the last substeps of its last step beyond the stop, and some lane of a wave
+        // does in most substeps (config 3's shape with this variant: 1.24 ms per launch when every such lane took the general
+        // two-row solve).  A lane at ONE stop takes that joint's closed form; only a lane at both takes the general solve
+        // (ip_limit_rows).  Which form a lane takes depends on its own state alone: its bits never depend on its wave-mates.
         bool hinge = false;
         if constexpr (VARIANT < 2) {
             static_assert(m.th_lo == -m.th_hi, "symmetric hinge range");
             hinge = fabs(th_old) > (R)m.th_hi;
         }
         if (__builtin_expect(VARIANT < 2 && __ballot(hinge) != 0ull, 0)) {
-            if (hinge) ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
-            else if (beyond) slider_row();
+            if (__builtin_expect(__ballot(hinge & beyond) != 0ull, 0)) {
+                if (hinge & beyond) ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
+            }
+            if (hinge & !beyond) limit_row(std::integral_constant<int, 1>{});
+            else if (beyond & !hinge) limit_row(std::integral_constant<int, 0>{});
         } else if (beyond) {
-            slider_row();
+            limit_row(std::integral_constant<int, 0>{});
         }
         s[2] = fma_r(dt, a0, v_old);  // MuJoCo Euler on qvel (no joint damping in this model)
         s[3] = fma_r(dt, a1, om_old);
