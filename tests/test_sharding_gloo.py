@@ -45,7 +45,8 @@ def _worker(rank, world, port, n_per_rank, q, algo="collective"):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (2, "direct"), (4, "direct"), (3, "direct")])
+@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (2, "direct"), (4, "direct"), (3, "direct"),
+                                        (8, "collective"), (8, "direct")])  # 8 = the ranks of BASELINE configs[4]
 def test_allgather_obs(world, algo):
     n = 96
     ctx = mp.get_context("spawn")
