@@ -93,7 +93,7 @@ def _xchg_worker(rank, world, port, q, algo="collective"):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (4, "direct")])
+@pytest.mark.parametrize("world,algo", [(2, "collective"), (4, "collective"), (4, "direct"), (8, "collective"), (8, "direct")])
 def test_obs_exchange_chunks(world, algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
