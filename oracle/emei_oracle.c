@@ -74,6 +74,55 @@ static void cp_ode_euler(double y[5], double dt, int steps) {
     }
 }
 
+/* base_control.py:133-173, "rk4" branch (:165-170) — unreachable from step() (:73 never passes `method`), callable directly:
+ *     k1 = np.asarray(derivs(y));  k2 = np.asarray(derivs(y + dt * k1 / 2));  k3 = ... k2 ...;  k4 = np.asarray(derivs(y + dt * k3))
+ *     y += (k1 + 2 * k2 + 2 * k3 + k4) * dt / 6
+ * NumPy 2 promotion, checked bit for bit against tests/golden/cartpole_rk4_golden.npz rather than reasoned out: the k's are
+ * float32 arrays and dt, 2, 6 weak Python scalars, so `dt * k` and `/ 2` round to float32, the stage state `y + ...` is a
+ * float64 sum of y and that float32 value, and the final combination is a chain of float32 roundings (2 k2; k1 + 2 k2;
+ * + 2 k3; + k4; * float32(dt); / 6) added to the float64 accumulator. */
+static void cp_ode_rk4(double y[5], double dt, int steps) {
+    const float dt32 = (float)dt;
+    for (int s = 0; s < steps; ++s) {
+        float k1[5], k2[5], k3[5], k4[5];
+        double ys[5];
+        cp_dsdt(y, k1);
+        for (int i = 0; i < 5; ++i) {
+            volatile float h = dt32 * k1[i];
+            volatile float h2 = h / 2.0f;
+            ys[i] = y[i] + (double)h2;
+        }
+        cp_dsdt(ys, k2);
+        for (int i = 0; i < 5; ++i) {
+            volatile float h = dt32 * k2[i];
+            volatile float h2 = h / 2.0f;
+            ys[i] = y[i] + (double)h2;
+        }
+        cp_dsdt(ys, k3);
+        for (int i = 0; i < 5; ++i) {
+            volatile float h = dt32 * k3[i];
+            ys[i] = y[i] + (double)h;
+        }
+        cp_dsdt(ys, k4);
+        for (int i = 0; i < 5; ++i) {
+            volatile float a = 2.0f * k2[i];
+            volatile float b = k1[i] + a;
+            volatile float c = 2.0f * k3[i];
+            volatile float d = b + c;
+            volatile float e = d + k4[i];
+            volatile float f = e * dt32;
+            volatile float g = f / 6.0f;
+            y[i] += (double)g;
+        }
+    }
+}
+
+/* method: 0 = "euler" (what step() runs), 1 = "rk4" (ODE_approximation's other branch) */
+static inline void cp_ode(double y[5], double dt, int steps, int method) {
+    if (method == 1) cp_ode_rk4(y, dt, steps);
+    else cp_ode_euler(y, dt, steps);
+}
+
 static inline double cp_x_threshold(int variant) { return variant == 0 ? 5.0 : 2.4; }
 static inline double cp_theta_threshold(void) { return 12 * 2 * M_PI / 360; } /* cartpole.py:30 */
 
@@ -94,18 +143,22 @@ static inline double cp_reward(int variant, const double* obs) {
 
 /* base_control.py:61-83 for a batch of independent envs.  state: [n,4] row-major float64, in/out.
  * action: {0,1}; force = +force_mag if action == 1 else -force_mag (cartpole.py:121-122,142-143). */
-EXPORT void emei_oracle_cartpole_step(int variant, int64_t n, int freq_rate, double dt, double* state,
-                                      const int32_t* action, double* reward, uint8_t* terminal) {
+EXPORT void emei_oracle_cartpole_step_method(int variant, int64_t n, int freq_rate, double dt, int method, double* state,
+                                             const int32_t* action, double* reward, uint8_t* terminal) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double y[5];
         memcpy(y, state + 4 * i, 4 * sizeof(double));
         y[4] = action[i] == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
-        cp_ode_euler(y, dt, freq_rate);
+        cp_ode(y, dt, freq_rate, method);
         memcpy(state + 4 * i, y, 4 * sizeof(double));
         reward[i] = cp_reward(variant, y);
         terminal[i] = cp_terminal(variant, y);
     }
+}
+EXPORT void emei_oracle_cartpole_step(int variant, int64_t n, int freq_rate, double dt, double* state,
+                                      const int32_t* action, double* reward, uint8_t* terminal) {
+    emei_oracle_cartpole_step_method(variant, n, freq_rate, dt, 0, state, action, reward, terminal);
 }
 
 EXPORT void emei_oracle_cartpole_reward(int variant, int64_t n, const double* obs, double* reward) {
@@ -200,9 +253,9 @@ EXPORT void emei_oracle_cartpole_init_f32(int variant, uint64_t seed, uint64_t e
  *   actions [T,n] uint8; outputs as the device writes them: obs [T,n,4] float32 (the state after the step, before any reset),
  *   reward [T,n] float32, done [T,n] uint8 (bit 0 terminal, bit 1 truncated); any output may be NULL.
  * Parallel over blocks of 64 envs (no per-step fork / join). */
-EXPORT void emei_oracle_cartpole_rollout_autoreset(int variant, int64_t n, int T, int freq_rate, double dt, int max_steps, uint64_t seed,
-                                                   const int64_t* env_ids, double* state, int32_t* steps, uint32_t* episode,
-                                                   const uint8_t* actions, float* obs, float* reward, uint8_t* done) {
+static void cartpole_rollout_autoreset_impl(int variant, int64_t n, int T, int freq_rate, double dt, int method, int max_steps, uint64_t seed,
+                                            const int64_t* env_ids, double* state, int32_t* steps, uint32_t* episode,
+                                            const uint8_t* actions, float* obs, float* reward, uint8_t* done) {
     /* blocks of envs (static over the threads), steps outermost inside a block: a block's state (64 envs x 32 B) stays in the
      * core's L1 and every output row is written in contiguous 64-env pieces */
     const int64_t BLK = 64, nblk = (n + BLK - 1) / BLK;
@@ -214,7 +267,7 @@ EXPORT void emei_oracle_cartpole_rollout_autoreset(int variant, int64_t n, int T
                 double y[5];
                 memcpy(y, state + 4 * i, 4 * sizeof(double));
                 y[4] = actions[(int64_t)t * n + i] == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
-                cp_ode_euler(y, dt, freq_rate);
+                cp_ode(y, dt, freq_rate, method);
                 const int32_t st = ++steps[i];
                 const uint8_t d = (uint8_t)(cp_terminal(variant, y) | ((max_steps > 0 && st >= max_steps) ? 2 : 0));
                 const int64_t row = (int64_t)t * n + i;
@@ -231,6 +284,17 @@ EXPORT void emei_oracle_cartpole_rollout_autoreset(int variant, int64_t n, int T
             }
         }
     }
+}
+
+EXPORT void emei_oracle_cartpole_rollout_autoreset(int variant, int64_t n, int T, int freq_rate, double dt, int max_steps, uint64_t seed,
+                                                   const int64_t* env_ids, double* state, int32_t* steps, uint32_t* episode,
+                                                   const uint8_t* actions, float* obs, float* reward, uint8_t* done) {
+    cartpole_rollout_autoreset_impl(variant, n, T, freq_rate, dt, 0, max_steps, seed, env_ids, state, steps, episode, actions, obs, reward, done);
+}
+EXPORT void emei_oracle_cartpole_rollout_autoreset_method(int variant, int64_t n, int T, int freq_rate, double dt, int method, int max_steps,
+                                                          uint64_t seed, const int64_t* env_ids, double* state, int32_t* steps,
+                                                          uint32_t* episode, const uint8_t* actions, float* obs, float* reward, uint8_t* done) {
+    cartpole_rollout_autoreset_impl(variant, n, T, freq_rate, dt, method, max_steps, seed, env_ids, state, steps, episode, actions, obs, reward, done);
 }
 
 #include "integrators.h"

@@ -284,6 +284,80 @@ def gen_cartpole(ref, out):
     return data
 
 
+def gen_cartpole_rk4(ref, out):
+    """The classic-control RK4 branch (base_control.py:165-170).  `step()` never reaches it (it calls ODE_approximation without
+    `method`, :73), so it is called directly, exactly as a user of the function would: ODE_approximation(env._dsdt, s_aug, dt,
+    steps, method="rk4").  Rows: one-step pairs over the wide state distribution of gen_cartpole, and seeded 1000-step open-loop
+    trajectories that follow step()'s own sequence (:61-83) with only the `method` argument added; reward / terminal are the
+    envs' own get_batch_reward / get_batch_terminal on the new state."""
+    from emei.envs.classic_control.base_control import ODE_approximation
+
+    envs = {"swingup": ref.cp.CartPoleSwingUpEnv, "balancing": ref.cp.CartPoleBalancingEnv}
+    data = {}
+    rng = np.random.default_rng(20245)
+
+    def rk4_step(env, action):
+        action = np.asarray(action)
+        pre_obs = env.state.copy()
+        s_aug = np.append(env.state, env._extract_action(action))
+        env.state = ODE_approximation(env._dsdt, s_aug, env.real_time_scale, env.freq_rate, method="rk4")[: len(env.state)]
+        obs = env.state.copy()
+        r = env.get_batch_reward(obs[None], pre_obs[None], action[None])[0, 0]
+        t = env.get_batch_terminal(obs[None], pre_obs[None], action[None])[0, 0]
+        return obs, r, t
+
+    n = 1024
+    for name, cls in envs.items():
+        s0 = wide_states(rng, n, name == "swingup")
+        act = rng.integers(2, size=n)
+        data[f"onestep_{name}_state"] = s0
+        data[f"onestep_{name}_action"] = act.astype(np.int64)
+        for fr, dt in ((1, 0.02), (4, 0.02), (2, 0.01)):
+            env = cls(freq_rate=fr, real_time_scale=dt)
+            env.reset(seed=0)
+            nxt = np.empty((n, 4))
+            rew = np.empty(n)
+            term = np.empty(n, dtype=bool)
+            raised = np.zeros(n, dtype=bool)
+            with np.errstate(all="ignore"):
+                for i in range(n):
+                    env.state = s0[i].copy()
+                    try:
+                        o, r, t = rk4_step(env, int(act[i]))
+                    except (ValueError, OverflowError):  # math.cos(+-inf) / float ** 2 overflow (cartpole.py:51-53): no result
+                        raised[i] = True
+                        nxt[i], rew[i], term[i] = np.nan, np.nan, True
+                        continue
+                    nxt[i], rew[i], term[i] = o, r, t
+            tag = f"onestep_{name}_fr{fr}_dt{dt}"
+            data[tag + "_raised"] = raised
+            data[tag + "_next"] = nxt
+            data[tag + "_reward"] = rew
+            data[tag + "_terminal"] = term
+
+    T = 1000
+    for name, cls in envs.items():
+        for fr in (1, 4):
+            for seed in range(4):
+                env = cls(freq_rate=fr, real_time_scale=0.02)
+                o0, _ = env.reset(seed=seed)
+                acts = np.random.default_rng(2000 + seed).integers(2, size=T)
+                traj = np.empty((T + 1, 4))
+                rew = np.empty(T)
+                term = np.empty(T, dtype=bool)
+                traj[0] = o0
+                with np.errstate(all="ignore"):
+                    for t in range(T):
+                        traj[t + 1], rew[t], term[t] = rk4_step(env, int(acts[t]))
+                tag = f"traj_{name}_fr{fr}_seed{seed}"
+                data[tag + "_actions"] = acts.astype(np.int64)
+                data[tag + "_states"] = traj
+                data[tag + "_reward"] = rew
+                data[tag + "_terminal"] = term
+    np.savez_compressed(os.path.join(out, "cartpole_rk4_golden.npz"), **data)
+    return data
+
+
 def gen_mujoco_firstparty(ref, out):
     """First-party helpers of the MuJoCo-backed classes, called unbound on a stand-in self."""
     data = {}
@@ -685,6 +759,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     ref = import_reference(a.ref)
     c = gen_cartpole(ref, a.out)
+    rk = gen_cartpole_rk4(ref, a.out)
     m = gen_mujoco_firstparty(ref, a.out)
     d = gen_dpend_firstparty(ref, a.out)
     h = gen_hopper_firstparty(ref, a.out)
@@ -696,7 +771,7 @@ def main():
     print("reset(seed=0):", o)
     for act in (0, 1, 1):
         print(env.step(act)[:3])
-    print("cartpole keys:", len(c), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg), " model-constant keys:", len(mc), " free-joint keys:", len(fj))
+    print("cartpole keys:", len(c), " cartpole-rk4 keys:", len(rk), " mujoco-firstparty keys:", len(m), " dpend-firstparty keys:", len(d), " hopper-firstparty keys:", len(h), " lagrange keys:", len(lg), " model-constant keys:", len(mc), " free-joint keys:", len(fj))
 
 
 if __name__ == "__main__":

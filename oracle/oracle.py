@@ -40,21 +40,25 @@ def _p(a, t):
 
 
 # --------------------------------------------------------------------------- CartPole (C)
-def cartpole_step(variant, state, action, freq_rate=1, dt=0.02):
-    """state [n,4] float64 (copied), action [n] int -> (next_state, reward, terminal)."""
+ODE_METHODS = {"euler": 0, "rk4": 1}  # ODE_approximation(method=) of base_control.py:133-173
+
+
+def cartpole_step(variant, state, action, freq_rate=1, dt=0.02, method="euler"):
+    """state [n,4] float64 (copied), action [n] int -> (next_state, reward, terminal).  method: the `method` argument of
+    ODE_approximation ("euler" is what step() runs, base_control.py:73; "rk4" the branch of :165-170)."""
     v = CARTPOLE_VARIANTS[variant]
     st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
     n = st.shape[0]
     act = np.ascontiguousarray(action, dtype=np.int32).reshape(n)
     rew = np.empty(n, np.float64)
     term = np.empty(n, np.uint8)
-    lib().emei_oracle_cartpole_step(
-        C.c_int(v), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)),
+    lib().emei_oracle_cartpole_step_method(
+        C.c_int(v), C.c_int64(n), C.c_int(int(freq_rate)), C.c_double(float(dt)), C.c_int(ODE_METHODS[method]),
         _p(st, C.c_double), _p(act, C.c_int32), _p(rew, C.c_double), _p(term, C.c_uint8))
     return st, rew, term.astype(bool)
 
 
-def cartpole_rollout(variant, state0, actions, freq_rate=1, dt=0.02):
+def cartpole_rollout(variant, state0, actions, freq_rate=1, dt=0.02, method="euler"):
     """Open-loop rollout without reset (base_control.py:61-83 never resets).
     actions [T,n] -> states [T+1,n,4], reward [T,n], terminal [T,n]."""
     st = np.array(state0, dtype=np.float64).reshape(-1, 4)
@@ -64,7 +68,7 @@ def cartpole_rollout(variant, state0, actions, freq_rate=1, dt=0.02):
     term = np.empty((T, st.shape[0]), bool)
     states[0] = st
     for t in range(T):
-        st, rew[t], term[t] = cartpole_step(variant, st, actions[t], freq_rate, dt)
+        st, rew[t], term[t] = cartpole_step(variant, st, actions[t], freq_rate, dt, method)
         states[t + 1] = st
     return states, rew, term
 
@@ -106,7 +110,7 @@ def cartpole_init_state_host(variant, seed, batch_size):
 
 
 def cartpole_rollout_autoreset(variant, state, actions, seed, env_ids=None, max_steps=0, freq_rate=1, dt=0.02, steps=None, episode=None,
-                               want=("obs", "reward", "done"), reuse=None):
+                               want=("obs", "reward", "done"), reuse=None, method="euler"):
     """T fused steps with device-style auto-reset, in C over all envs (the CPU twin of emei_rollout with EMEI_FLAG_AUTO_RESET).
     state [n,4] float64 (copied), actions [T,n] uint8 -> dict(obs [T,n,4] f32, reward [T,n] f32, done [T,n] u8, state [n,4] f64,
     steps [n] i32, episode [n] u32); `want` selects which per-step outputs are produced; `reuse` = the dict of a previous call
@@ -124,8 +128,9 @@ def cartpole_rollout_autoreset(variant, state, actions, seed, env_ids=None, max_
         obs = np.empty((T, n, 4), np.float32) if "obs" in want else None
         rew = np.empty((T, n), np.float32) if "reward" in want else None
         dn = np.empty((T, n), np.uint8) if "done" in want else None
-    lib().emei_oracle_cartpole_rollout_autoreset(
-        C.c_int(CARTPOLE_VARIANTS[variant]), C.c_int64(n), C.c_int(T), C.c_int(int(freq_rate)), C.c_double(float(dt)), C.c_int(int(max_steps)),
+    lib().emei_oracle_cartpole_rollout_autoreset_method(
+        C.c_int(CARTPOLE_VARIANTS[variant]), C.c_int64(n), C.c_int(T), C.c_int(int(freq_rate)), C.c_double(float(dt)), C.c_int(ODE_METHODS[method]),
+        C.c_int(int(max_steps)),
         C.c_uint64(int(seed)), _p(ids, C.c_int64) if ids is not None else None, _p(st, C.c_double), _p(sc, C.c_int32), _p(ep, C.c_uint32),
         _p(act, C.c_uint8), _p(obs, C.c_float) if obs is not None else None, _p(rew, C.c_float) if rew is not None else None,
         _p(dn, C.c_uint8) if dn is not None else None)

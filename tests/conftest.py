@@ -32,6 +32,12 @@ def cartpole_golden():
 
 
 @pytest.fixture(scope="session")
+def cartpole_rk4_golden():
+    """ODE_approximation(..., method="rk4") of the reference (base_control.py:165-170), called directly (oracle/gen_golden.py)."""
+    return np.load(os.path.join(GOLDEN, "cartpole_rk4_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def mujoco_golden():
     return np.load(os.path.join(GOLDEN, "mujoco_firstparty_golden.npz"))
 

@@ -39,6 +39,38 @@ def test_cartpole_trajectory_bit_exact(cartpole_golden, name, fr, seed):
     assert rel_err(rew[:, 0], g[tag + "_reward"], floor=1e-300) <= 4e-16
 
 
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr,dt", [(1, 0.02), (4, 0.02), (2, 0.01)])
+def test_cartpole_rk4_onestep_bit_exact(cartpole_rk4_golden, name, fr, dt):
+    """The classic-control RK4 branch (base_control.py:165-170), the reference's float32 / float64 promotion chain bit for bit."""
+    g = cartpole_rk4_golden
+    tag = f"onestep_{name}_fr{fr}_dt{dt}"
+    ok = ~g[tag + "_raised"]
+    nxt, rew, term = O.cartpole_step(name, g[f"onestep_{name}_state"], g[f"onestep_{name}_action"], fr, dt, method="rk4")
+    assert _same(nxt[ok], g[tag + "_next"][ok])
+    assert np.array_equal(term[ok], g[tag + "_terminal"][ok])
+    assert rel_err(rew[ok], g[tag + "_reward"][ok], floor=1e-300) <= 4e-16
+
+
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+@pytest.mark.parametrize("fr", [1, 4])
+@pytest.mark.parametrize("seed", range(4))
+def test_cartpole_rk4_trajectory_bit_exact(cartpole_rk4_golden, name, fr, seed):
+    g = cartpole_rk4_golden
+    tag = f"traj_{name}_fr{fr}_seed{seed}"
+    st, rew, term = O.cartpole_rollout(name, g[tag + "_states"][:1], g[tag + "_actions"][:, None], fr, 0.02, method="rk4")
+    assert _same(st[:, 0], g[tag + "_states"])
+    assert np.array_equal(term[:, 0], g[tag + "_terminal"])
+    assert rel_err(rew[:, 0], g[tag + "_reward"], floor=1e-300) <= 4e-16
+
+
+def test_cartpole_rk4_differs_from_euler(cartpole_golden, cartpole_rk4_golden):
+    """... and is not the Euler branch under another name: same start, same actions, a different trajectory."""
+    g = cartpole_rk4_golden
+    st_e, _, _ = O.cartpole_rollout("swingup", g["traj_swingup_fr1_seed0_states"][:1], g["traj_swingup_fr1_seed0_actions"][:, None], 1, 0.02)
+    assert np.abs(st_e[100, 0] - g["traj_swingup_fr1_seed0_states"][100]).max() > 1e-4
+
+
 def test_baseline_md_first_rows(cartpole_golden):
     """The values quoted in BASELINE.md / SURVEY.md 8c: reset(seed=0) then actions 0, 1, 1."""
     s0 = O.cartpole_init_state_host("swingup", 0, 1)
