@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--solver", default="newton", choices=["newton", "sweep1"],
                     help="constraint solver of the HalfCheetah / Hopper workloads: MuJoCo's formulation solved to convergence "
                          "(default) or round 1's single Gauss-Seidel sweep")
+    ap.add_argument("--rollout-chunk-steps", type=int, default=0,
+                    help="body rollouts as (64 envs) x (k steps) work items: 0 = automatic (the default), -1 = one-piece launches, "
+                         "k > 0 = k steps per item (emei_config.rollout_chunk_steps); results do not depend on it")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed clock-settle phase before the warm-up passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
@@ -262,7 +265,7 @@ def main():
     sr = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision,
                         rank=rank, world=world, device=local_rank, seed=0,
                         integrator=a.integrator or w.get("integrator", "euler"), gather=gather, chunk=chunk, solver=a.solver,
-                        exchange_algo=a.exchange)
+                        exchange_algo=a.exchange, rollout_chunk_steps=a.rollout_chunk_steps)
     desc = w["desc"]
     if sharded_cartpole and a.workload == "cartpole_swingup" and N == MULTI_GPU_SHARD:
         desc = (f"CartPoleSwingUp-v0, {world * N} parallel envs sharded {world}xMI355X ({N} per GPU) with RCCL all-gather of obs"

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 #include "launch.h"
@@ -30,6 +31,8 @@ struct emei_env {
     uint32_t* frozen_episode;
     uint64_t frozen_seed;          // key of the reset generator at emei_freeze (restored by emei_unfreeze)
     unsigned long long* cap_hits;  // device counter: Newton solves that ended at the iteration cap (emei_get_solver_cap_hits)
+    uint32_t* work;                // body_kernels.h:WorkQueue words of the chunked body rollout (2 + waves of the shard)
+    int resident_waves;            // waves of this handle's body rollout kernel the device holds at once (0: not a body / unknown)
     bool has_state, frozen;
     int last_kernel;  // enum emei_kernel_id of the last emei_step / emei_rollout
     uint32_t* host_flag = nullptr;  // emei_step_host: page-locked completion word (allocated on first use) ...
@@ -207,9 +210,11 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (!cfg || !out) return fail(EMEI_ERR_INVALID, "emei_create: null argument");
     // older callers pass a shorter struct: every tail field has an all-zero default
     const uint32_t size_v2a = (uint32_t)offsetof(emei_config, env_param_mask);  // 328: before env_params existed
-    if (cfg->struct_size != sizeof(emei_config) && cfg->struct_size != size_v2a && cfg->struct_size != EMEI_CONFIG_SIZE_V1)
-        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu (or the older sizes %u / %u)",
-                    cfg->struct_size, sizeof(emei_config), size_v2a, EMEI_CONFIG_SIZE_V1);
+    const uint32_t size_v5 = (uint32_t)offsetof(emei_config, ode_method);       // 400: before ode_method / rollout_chunk_steps
+    if (cfg->struct_size != sizeof(emei_config) && cfg->struct_size != size_v5 && cfg->struct_size != size_v2a &&
+        cfg->struct_size != EMEI_CONFIG_SIZE_V1)
+        return fail(EMEI_ERR_INVALID, "emei_create: emei_config size %u, library expects %zu (or the older sizes %u / %u / %u)",
+                    cfg->struct_size, sizeof(emei_config), size_v5, size_v2a, EMEI_CONFIG_SIZE_V1);
     emei_config c2;  // the caller's struct, widened to this library's layout
     memset(&c2, 0, sizeof(c2));
     memcpy(&c2, cfg, cfg->struct_size);
@@ -224,6 +229,12 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     for (int i = 0; i < EMEI_MAX_STATE_DIM; ++i)
         if (!(cfg->init_sigma[i] >= 0) || !(cfg->obs_sigma[i] >= 0))
             return fail(EMEI_ERR_INVALID, "emei_create: noise sigmas must be >= 0");
+    if (cfg->ode_method != EMEI_ODE_EULER && cfg->ode_method != EMEI_ODE_RK4)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_create: ode_method=%d", cfg->ode_method);  // base_control.py:171-172
+    if (cfg->ode_method != EMEI_ODE_EULER && cfg->env_id != EMEI_CARTPOLE_SWINGUP && cfg->env_id != EMEI_CARTPOLE_BALANCING)
+        return fail(EMEI_ERR_INVALID, "emei_create: ode_method is ODE_approximation's switch (classic control); env_id %d is integrated "
+                    "according to `integrator`", cfg->env_id);
+    if (cfg->rollout_chunk_steps < -1 && (cfg->rollout_chunk_steps > -101 || cfg->rollout_chunk_steps < -106)) return fail(EMEI_ERR_INVALID, "emei_create: rollout_chunk_steps=%d", cfg->rollout_chunk_steps);
     if (cfg->solver != EMEI_SOLVER_NEWTON && cfg->solver != EMEI_SOLVER_SWEEP1) return fail(EMEI_ERR_INVALID, "emei_create: solver=%u", cfg->solver);
     if (cfg->env_param_mask >> EMEI_MAX_ENV_PARAMS) return fail(EMEI_ERR_INVALID, "emei_create: env_param_mask=0x%x", cfg->env_param_mask);
     if (cfg->env_param_mask != 0 && cfg->env_id != EMEI_HALFCHEETAH_RUNNING && cfg->env_id != EMEI_HOPPER_RUNNING)
@@ -266,6 +277,10 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->frozen_episode, n * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&h->cap_hits, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->cap_hits, 0, sizeof(unsigned long long));
+    if (e == hipSuccess && steps_as_body(*cfg)) {
+        e = hipMalloc((void**)&h->work, (2 + n_words) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(h->work, 0, (2 + n_words) * sizeof(uint32_t));
+    }
     if (e == hipSuccess) e = hipMemset(h->done_mask, 0, n_words * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->steps, 0, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(h->episode, 0, n * sizeof(uint32_t));
@@ -279,6 +294,12 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (!h->trig) {
         emei_destroy(h);
         return fail(EMEI_ERR_HIP, "emei_create: could not build the trig table on device %d", cfg->device);
+    }
+    if (steps_as_body(*cfg)) {  // occupancy of the rollout kernel: the automatic chunking policy (body_kernels.h:WorkQueue)
+        BodyLaunch L;
+        L.op = BODY_OP_OCCUPANCY, L.env_id = cfg->env_id, L.precision = cfg->precision, L.integrator = cfg->integrator;
+        L.solver = (int)cfg->solver, L.selected = &h->resident_waves;
+        if (body_launch(L) != EMEI_OK) h->resident_waves = 0;  // unknown: the automatic policy then stays with one-piece launches
     }
     *out = h;
     return EMEI_OK;
@@ -294,6 +315,7 @@ extern "C" EMEI_API int emei_destroy(emei_env* h) {
     (void)hipFree(h->frozen_steps);
     (void)hipFree(h->frozen_episode);
     (void)hipFree(h->cap_hits);
+    (void)hipFree(h->work);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
     delete h;
     return EMEI_OK;
@@ -317,6 +339,7 @@ static PendLaunch pend_base(emei_env* h, void* stream) {
     PendLaunch L;
     L.env_id = h->cfg.env_id;
     L.precision = h->cfg.precision;
+    L.ode_method = h->cfg.ode_method;
     L.state = h->state;
     L.steps = h->steps;
     L.episode = h->episode;
@@ -355,6 +378,7 @@ static BodyLaunch body_base(emei_env* h, void* stream) {
     memcpy(L.env_params.v, h->cfg.env_params, sizeof(L.env_params.v));
     L.trig = h->trig;
     L.cap_hits = h->cap_hits;
+    L.work = h->work, L.chunk_steps = h->cfg.rollout_chunk_steps, L.resident_waves = h->resident_waves;
     L.stream = (hipStream_t)stream;
     return L;
 }
@@ -463,6 +487,15 @@ extern "C" EMEI_API int emei_get_solver_cap_hits(emei_env* h, uint64_t* count_ou
     return EMEI_OK;
 }
 
+extern "C" EMEI_API int emei_get_rollout_faults(emei_env* h, uint64_t* count_out, void* stream) {
+    if (!h || !count_out) return fail(EMEI_ERR_INVALID, "emei_get_rollout_faults: null argument");
+    EMEI_ON_DEVICE(h, "emei_get_rollout_faults");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(count_out, 0, sizeof(uint64_t), s));
+    if (h->work) HIP_TRY(hipMemcpyAsync(count_out, h->work + WorkQueue::kFaults, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));  // little endian
+    return EMEI_OK;
+}
+
 static int check_action_dtype(const emei_env* h, int action_dtype) {
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype %d", action_dtype);
     int od, ad, sd;
@@ -541,12 +574,22 @@ extern "C" EMEI_API int emei_step_host(emei_env* h, const void* actions_host, in
         // poll the word (the kernel's last store, system scope); a launch that does not finish within ~5 ms is handed to the
         // runtime's own wait, which also surfaces a device fault
         volatile uint32_t* flag = h->host_flag;
-        for (int spin = 0; spin < 4000000; ++spin) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int spin = 0;; ++spin) {
             if (*flag == L.flag_value) {
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 return EMEI_OK;
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            __asm__ __volatile__("" ::: "memory");
+#endif
+            if ((spin & 1023) == 1023) {  // the bound is wall time (a pause is 40-140 cycles depending on the part), checked every 1024 spins
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 5000000ll) break;
+            }
         }
         HIP_TRY(hipStreamSynchronize(s));
         return *flag == L.flag_value ? EMEI_OK : fail(EMEI_ERR_HIP, "emei_step_host: the kernel finished without its completion word");
@@ -736,6 +779,8 @@ extern "C" EMEI_API int emei_next_obs_io(int env_id, int64_t n, int io_dtype, co
     if (!(real_time_scale > 0) || freq_rate < 1) return fail(EMEI_ERR_INVALID, "emei_next_obs: bad dt/freq_rate");
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype");
     if (precision != EMEI_PRECISION_REF && precision != EMEI_PRECISION_F32) return fail(EMEI_ERR_INVALID, "emei_next_obs: precision=%d", precision);
+    const int ode_method = (integrator & EMEI_NEXT_OBS_ODE_RK4) ? EMEI_ODE_RK4 : EMEI_ODE_EULER;  // classic control only
+    integrator &= ~EMEI_NEXT_OBS_ODE_RK4;
     if (integrator < EMEI_INTEG_EULER || integrator > EMEI_INTEG_RK4)
         return fail(EMEI_ERR_UNSUPPORTED, "emei_next_obs: integrator=%d", integrator);
     int od, ad, sd;
@@ -747,6 +792,7 @@ extern "C" EMEI_API int emei_next_obs_io(int env_id, int64_t n, int io_dtype, co
         L.op = PEND_OP_NEXT_OBS;
         L.env_id = env_id;
         L.precision = precision;
+        L.ode_method = ode_method;
         L.obs_in = obs;
         L.io_f64 = io_dtype == EMEI_IO_F64;
         L.actions = actions;

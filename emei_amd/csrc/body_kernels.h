@@ -159,7 +159,8 @@ __device__ __forceinline__ void body_substep(typename Body::real (&s)[Body::NS],
     }
 }
 
-enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL, BODY_OP_NEXT_OBS };
+enum BodyOp { BODY_OP_ROLLOUT = 0, BODY_OP_RESET, BODY_OP_GET_OBS, BODY_OP_INIT_OBS, BODY_OP_REWARD, BODY_OP_TERMINAL, BODY_OP_NEXT_OBS,
+              BODY_OP_OCCUPANCY /* host only: *selected = waves of the rollout kernel (of L.integrator) the current device holds at once */ };
 
 // host-side launch descriptor (abi.hip -> body_dispatch.hip -> body_tu.hip)
 struct BodyLaunch {
@@ -190,6 +191,10 @@ struct BodyLaunch {
     EnvParams env_params;
     const void* trig = nullptr;
     unsigned long long* cap_hits = nullptr;  // device counter of the handle
+    // chunked rollout (emei_config.rollout_chunk_steps): the handle's work-queue words (see WorkQueue) and its policy
+    uint32_t* work = nullptr;
+    int32_t chunk_steps = 0;   // 0 = automatic, -1 = off, k > 0 = k steps per work item
+    int32_t resident_waves = 0;  // waves of the rollout kernel the device holds at once (automatic policy); 0 = unknown
     hipStream_t stream = nullptr;
     int* selected = nullptr;  // out: enum emei_kernel_id of the rollout kernel launched
 };
@@ -213,7 +218,64 @@ struct BodyArgs {
     NoiseArgs<Body::NS> noise;
     const SinCosEntry* trig;  // 256-entry {sin,cos} table of this device (abi.hip:emei_trig_table)
     unsigned long long* cap_hits;  // handle counter (emei_device.h:report_cap_hit)
+    uint32_t* work;        // chunked rollout: WorkQueue words of the handle (null = one-piece launch, block b = env-wave b)
+    int32_t chunk_steps;   // > 0: steps per work item; < 0: the guided schedule (WorkQueue::item_steps)
+    uint32_t n_waves;      // env-waves of the shard = work items per chunk
+    uint32_t n_items;      // n_waves x chunks: tickets at or beyond it end a worker
     typename Body::Model m;
+};
+
+// Chunked rollout of the bodies that run ONE wave per SIMD (one-wave blocks).  Why: at 131 072 envs a launch is two rounds of 1024
+// waves whose durations differ by their lanes' contact histories; a SIMD that finishes its two waves early idles until the
+// slowest pair of the launch ends (config 4: 10-14 % of the SIMD-time, profiles/r05_cheetah_tail.txt).  The launch is cut
+// into items of (one env-wave) x (chunk_steps steps) and launched as PERSISTENT one-wave workers, as many as the device
+// holds at once.  A worker draws a TICKET (atomic counter), works on item `ticket`, chunk-major:
+//     chunk = ticket / n_waves,  env-wave = ticket % n_waves,
+// and draws again until the tickets run out.  (First built as one block per item, refilled by the hardware dispatcher: the
+// hand-over from a finished block to the next cost the cheetah ~6 us of idle SIMD per item, profiles/r05_cheetah_tail.txt.)
+// Item (c, w) needs the state item (c - 1, w) leaves in the handle's arrays: it waits until progress[w] >= c, which (c - 1, w)
+// publishes — release at agent scope, the state stores of all 64 lanes ordered before it — when it is done.  No deadlock:
+// tickets are handed out in START order, so the item a block waits for has a smaller ticket, has therefore started, and itself
+// only ever waits for still smaller tickets (a worker holds ONE ticket at a time: drawing the next one early would let a
+// drawn-but-unstarted item block others).  The wait is bounded all the same (2 s of the 100 MHz counter, then the item is
+// skipped, counted in `faults`, and its progress word published so that its successors do not wait in turn), and a worker
+// ends at the first ticket beyond the last item: every wave reaches an exit.  A worker that finishes an item early takes the
+// next ticket: that is the dynamic balancing; the state round trip between items is 2 x 18 doubles per env per chunk against
+// 101 B x chunk_steps of outputs.
+// Results are bit-identical to the one-piece launch: an item runs the same per-step code from the same state
+// (tests/test_gpu_shapes.py: a fused rollout, its chunks and its single steps agree bit for bit).
+struct WorkQueue {
+    // word offsets; [kProgress + w] = chunks of env-wave w that are done.  The fault count is sticky, the words behind it are
+    // zeroed (one memset) in front of every chunked launch
+    enum { kFaults = 0, kTicket = 1, kProgress = 2 };
+    static constexpr unsigned long long kWaitTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
+    // Step range [t_begin, t_end) of chunk `chunk`.  chunk_steps > 0: fixed length.  chunk_steps = -g < 0: the GUIDED schedule —
+    // every chunk takes 1 / 2^g of the steps that remain (at least one): long items first, where a worker's finishing time does
+    // not matter and the per-item cost (ticket, state round trip, release: ~4 us) is paid rarely, short items last, where
+    // the launch ends with the slowest worker's LAST item (100 steps, g = 2: 25 19 14 11 8 6 5 3 3 2 1 1 1 1 = 14 items
+    // instead of the 20 of a fixed length 5, and a last item of one step).  Host and device run the same recurrence.
+    __host__ __device__ static void item_steps(int n_steps, int chunk_steps, uint32_t chunk, int& t_begin, int& t_end) {
+        if (chunk_steps > 0) {
+            t_begin = (int)chunk * chunk_steps;
+            t_end = t_begin + chunk_steps < n_steps ? t_begin + chunk_steps : n_steps;
+            return;
+        }
+        const int g = -chunk_steps;
+        int t = 0, len = 0;
+        for (uint32_t c = 0;; ++c) {
+            len = (n_steps - t + (1 << g) - 1) >> g;
+            len = len < 1 ? 1 : len;
+            if (c == chunk) break;
+            t += len;
+        }
+        t_begin = t, t_end = t + len < n_steps ? t + len : n_steps;
+    }
+    __host__ static unsigned count_chunks(int n_steps, int chunk_steps) {
+        if (chunk_steps > 0) return (unsigned)((n_steps + chunk_steps - 1) / chunk_steps);
+        unsigned c = 0;
+        for (int b = 0, e = 0; e < n_steps; ++c) item_steps(n_steps, chunk_steps, c, b, e);
+        return c;
+    }
 };
 
 // emei_step / emei_rollout (mujoco_env.py:157-167) for every env of the shard
@@ -235,9 +297,16 @@ __host__ __device__ constexpr int rollout_block() {
 #endif
 }
 
-template <class Body, bool RK4>
+#ifndef EMEI_WORKQUEUE
+#define EMEI_WORKQUEUE 1  // -DEMEI_WORKQUEUE=0: a variant build without the chunked-launch code, for A/B runs (tools/ab.sh)
+#endif
+// QUEUE: the persistent-worker form of a chunked launch (WorkQueue), its own instantiation so that the one-piece kernel is
+// instruction for instruction what it was without it (the item loop around the rollout costs the cheetah 1.7 %: scalar
+// registers held across it are spilled to VGPR lanes)
+template <class Body, bool RK4, bool QUEUE = false>
 __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEU)))
     body_rollout_kernel(const BodyArgs<Body> a) {
+    static_assert(!QUEUE || rollout_block<Body>() == kWave, "work items are one-wave blocks");
     using R = typename Body::real;
     constexpr int NS = Body::NS, NO = Body::NO, NA = Body::NA;
     constexpr int kBlock = rollout_block<Body>();  // shadows the library-wide 256 inside this kernel
@@ -255,9 +324,54 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     trig.scratch_stride = kBlock;
     trig.cap_hits = a.cap_hits;
     EMEI_PROFILE_BEGIN();
-    EMEI_CLOCK_BEGIN();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    constexpr bool kQueue = QUEUE;
+    // One pass of this loop = one (env block, step range): the whole horizon of block blockIdx.x, then out — or (QUEUE) one
+    // drawn item after the other until the tickets run out (WorkQueue: the block is a persistent worker).
+    uint32_t ticket = 0;
+    [[maybe_unused]] bool first_item = true;  // probe builds only
+    if constexpr (kQueue) {
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.work + WorkQueue::kTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma nounroll
+    for (;;) {
+    EMEI_CLOCK_BEGIN();
+    uint32_t blk = blockIdx.x, chunk = 0;
+    int t_begin = 0, t_end = a.n_steps;
+    if constexpr (kQueue) {
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket >= a.n_items) {  // the exit every worker reaches: tickets only grow
+            EMEI_CLOCK_WORKER_EXIT();
+            break;
+        }
+        if (first_item) EMEI_CLOCK_FIRST_ITEM();
+        first_item = false;
+        chunk = ticket / a.n_waves, blk = ticket - chunk * a.n_waves;
+        WorkQueue::item_steps(a.n_steps, a.chunk_steps, chunk, t_begin, t_end);
+        bool gave_up = false;
+        if (chunk > 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            // the acquire (agent scope: the predecessor may have run on another XCD, behind another L2) orders every
+            // load below after the predecessor's state stores
+            while (__hip_atomic_load(a.work + WorkQueue::kProgress + blk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+                __builtin_amdgcn_s_sleep(16);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > WorkQueue::kWaitTicks) {
+                    gave_up = true;
+                    break;
+                }
+            }
+            EMEI_CLOCK_WAITED(__builtin_amdgcn_s_memrealtime() - t0);
+        }
+        if (__builtin_expect(gave_up, 0)) {  // wave-uniform
+            if (lane == 0) {
+                __hip_atomic_fetch_add(a.work + WorkQueue::kFaults, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.work + WorkQueue::kProgress + blk, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = __hip_atomic_fetch_add(a.work + WorkQueue::kTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+    }
+    const int64_t i = (int64_t)blk * kBlock + threadIdx.x;
     const int64_t n = a.n;
     const int64_t i0 = i - lane;                             // first env of this wave
     const int wave_envs = (int)min((int64_t)kWave, n - i0);  // ragged last wave
@@ -308,15 +422,15 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     // a one-float action is already one coalesced dword per lane: no staging, fetched a step ahead
     float a_next = 0.f;
     if constexpr (NA == 1) {
-        if (active) a_next = a.actions[i];
+        if (active) a_next = a.actions[(int64_t)t_begin * n + i];
     } else {
-        fetch_actions(0);
+        fetch_actions(t_begin);
     }
-    for (int t = 0; t < a.n_steps; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         R ctrl[NA];
         if constexpr (NA == 1) {
             ctrl[0] = (R)a_next;
-            if (active && t + 1 < a.n_steps) a_next = a.actions[(int64_t)(t + 1) * n + i];
+            if (active && t + 1 < t_end) a_next = a.actions[(int64_t)(t + 1) * n + i];
         } else {
             // stage this step's actions through LDS, then prefetch the next step's block
 #pragma unroll
@@ -325,7 +439,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
 #pragma unroll
             for (int k = 0; k < NA; ++k) ctrl[k] = (R)act_s[wv][lane * NA + k];
             wave_lds_fence();  // the block is consumed before the next step overwrites it
-            if (t + 1 < a.n_steps) fetch_actions(t + 1);
+            if (t + 1 < t_end) fetch_actions(t + 1);
         }
 
         R pre[NS];
@@ -402,7 +516,17 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
     }
     unsigned long long mk = __ballot(done != 0);
     if (lane == 0 && active) a.done_mask[i / kWave] = mk;
+    if constexpr (kQueue) {
+        // publish this item: every lane's state stores, then the progress word (WorkQueue).  The next ticket is drawn BEFORE the
+        // release fence waits for those stores (its round trip to the L2 overlaps theirs): still one unfinished item per
+        // worker — this one, which nothing can hold up any more.
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.work + WorkQueue::kTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(a.work + WorkQueue::kProgress + blk, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     EMEI_CLOCK_END();
+    if constexpr (!kQueue) break;
+    }  // item loop
     EMEI_PROFILE_END();
 }
 
@@ -547,12 +671,61 @@ static int launch_body(const BodyLaunch& L) {
             a.semi = L.integrator == EMEI_INTEG_SEMI_IMPLICIT, a.noise = NoiseArgs<Body::NS>(L.noise);
             a.trig = (const SinCosEntry*)L.trig;
             a.cap_hits = L.cap_hits;
-            if (L.integrator == EMEI_INTEG_RK4)
-                hipLaunchKernelGGL((body_rollout_kernel<Body, true>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
-            else
-                hipLaunchKernelGGL((body_rollout_kernel<Body, false>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
-            if (L.selected) *L.selected = L.integrator == EMEI_INTEG_RK4 ? EMEI_KERNEL_BODY_RK4 : EMEI_KERNEL_BODY;
+            a.work = nullptr, a.chunk_steps = 0, a.n_waves = rgrid.x, a.n_items = 0;
+            if constexpr (rollout_block<Body>() == kWave && EMEI_WORKQUEUE != 0) {
+                // chunked launch (WorkQueue).  Automatic policy (0): only when the shard has more waves than the device holds at
+                // once (otherwise every wave is resident from the start and there is nothing to balance), the guided schedule
+                // with a quarter of the remaining steps per item.  emei_config encodes: k > 0 fixed length, -1 off, and — for
+                // experiments — -(100 + g): the guided schedule with 1 / 2^g
+                int cs = L.chunk_steps;
+                if (cs == 0) cs = (L.resident_waves > 0 && (int64_t)rgrid.x > L.resident_waves) ? -2 : 0;
+                else if (cs <= -100) cs = -min(-cs - 100, 6);
+                else if (cs < 0) cs = 0;
+                const unsigned n_chunks = cs != 0 ? WorkQueue::count_chunks(L.n_steps, cs) : 1u;
+                if (L.work && n_chunks > 1 && (uint64_t)rgrid.x * n_chunks < (1ull << 31)) {
+                    // ticket, progress words back to zero (the fault count is sticky), in stream order: capturable
+                    static_assert(WorkQueue::kProgress == WorkQueue::kTicket + 1, "one memset");
+                    if (hipMemsetAsync(L.work + WorkQueue::kTicket, 0, (size_t)(1 + rgrid.x) * sizeof(uint32_t), L.stream) != hipSuccess)
+                        return EMEI_ERR_HIP;
+                    a.work = L.work, a.chunk_steps = cs, a.n_items = rgrid.x * n_chunks;
+                    // persistent workers: as many one-wave blocks as the device holds at once (any count is correct: a
+                    // worker that starts late simply finds fewer tickets left)
+                    const unsigned workers = L.resident_waves > 0 ? (unsigned)L.resident_waves : 1024u;
+                    rgrid.x = min(workers, a.n_items);
+                    if (L.integrator == EMEI_INTEG_RK4)
+                        hipLaunchKernelGGL((body_rollout_kernel<Body, true, true>), rgrid, dim3(kWave), 0, L.stream, a);
+                    else
+                        hipLaunchKernelGGL((body_rollout_kernel<Body, false, true>), rgrid, dim3(kWave), 0, L.stream, a);
+                }
+            }
+            if (!a.work) {
+                if (L.integrator == EMEI_INTEG_RK4)
+                    hipLaunchKernelGGL((body_rollout_kernel<Body, true>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
+                else
+                    hipLaunchKernelGGL((body_rollout_kernel<Body, false>), rgrid, dim3(rollout_block<Body>()), 0, L.stream, a);
+            }
+            if (L.selected)
+                *L.selected = a.work ? (L.integrator == EMEI_INTEG_RK4 ? EMEI_KERNEL_BODY_RK4_CHUNKED : EMEI_KERNEL_BODY_CHUNKED)
+                                     : (L.integrator == EMEI_INTEG_RK4 ? EMEI_KERNEL_BODY_RK4 : EMEI_KERNEL_BODY);
             break;
+        }
+        case BODY_OP_OCCUPANCY: {
+            int dev = 0, cus = 0, nb = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                return EMEI_ERR_HIP;
+            hipError_t e;
+            if constexpr (rollout_block<Body>() == kWave && EMEI_WORKQUEUE != 0) {  // the persistent workers' own instantiation
+                e = L.integrator == EMEI_INTEG_RK4
+                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, body_rollout_kernel<Body, true, true>, rollout_block<Body>(), 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, body_rollout_kernel<Body, false, true>, rollout_block<Body>(), 0);
+            } else {
+                e = L.integrator == EMEI_INTEG_RK4
+                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, body_rollout_kernel<Body, true>, rollout_block<Body>(), 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, body_rollout_kernel<Body, false>, rollout_block<Body>(), 0);
+            }
+            if (e != hipSuccess) return EMEI_ERR_HIP;
+            if (L.selected) *L.selected = nb * cus * (rollout_block<Body>() / kWave);
+            return EMEI_OK;
         }
         case BODY_OP_RESET:
             hipLaunchKernelGGL(body_reset_kernel<Body>, grid, dim3(kBlock), 0, L.stream, (R*)L.state, L.steps, L.episode,

@@ -35,14 +35,39 @@ struct ClockProbe {
         const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
         if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {
             atomicAdd(&g_debug_stats[28], c1 - c0), atomicAdd(&g_debug_stats[29], r1 - r0), atomicAdd(&g_debug_stats[30], 1ull);
+            // round 5 (tools/tail_probe.py): the span of the launch(es) in the same 100 MHz ticks — latest end in slot 27, earliest
+            // begin as the maximum of its complement in slot 31 (both start from the cleared 0) — so that utilisation is a ratio
+            // of two readings of ONE counter; slot 26: ticks spent waiting for a predecessor work item (body_kernels.h:WorkQueue)
+            atomicMax(&g_debug_stats[27], r1), atomicMax(&g_debug_stats[31], ~r0);
+            atomicMax(&g_debug_stats[23], r1 - r0);  // the longest single lifetime
         }
+    }
+    // a persistent worker leaves (no ticket left): slot 21 workers, slot 22 the sum of their exit ticks — the mean exit against the
+    // last end (slot 27) is the drain of the launch
+    __device__ __forceinline__ static void worker_exit() {
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_debug_stats[21], 1ull), atomicAdd(&g_debug_stats[22], r);
+    }
+    // persistent workers (body_kernels.h:WorkQueue): how many of them got at least one item (slot 24), and when the last of them
+    // began its first (slot 25, the same ticks): workers that are not resident from the start of the launch show up here
+    __device__ __forceinline__ void first_item() const {
+        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_debug_stats[24], 1ull), atomicMax(&g_debug_stats[25], r0);
+    }
+    __device__ __forceinline__ void waited(unsigned long long ticks) const {
+        if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) atomicAdd(&g_debug_stats[26], ticks);
     }
 };
 #define EMEI_CLOCK_BEGIN() emei::ClockProbe clock_probe_; clock_probe_.begin()
 #define EMEI_CLOCK_END() clock_probe_.end()
+#define EMEI_CLOCK_WAITED(t) clock_probe_.waited(t)
+#define EMEI_CLOCK_FIRST_ITEM() clock_probe_.first_item()
+#define EMEI_CLOCK_WORKER_EXIT() emei::ClockProbe::worker_exit()
 #else
 #define EMEI_CLOCK_BEGIN() ((void)0)
 #define EMEI_CLOCK_END() ((void)0)
+#define EMEI_CLOCK_WAITED(t) ((void)0)
+#define EMEI_CLOCK_FIRST_ITEM() ((void)0)
+#define EMEI_CLOCK_WORKER_EXIT() ((void)0)
 #endif
 #ifdef EMEI_NEWTON_STATS
 static __device__ unsigned long long g_debug_stats[32];

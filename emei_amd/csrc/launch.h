@@ -12,6 +12,7 @@ enum PendOp { PEND_OP_ROLLOUT = 0, PEND_OP_RESET, PEND_OP_GET_OBS, PEND_OP_REWAR
 struct PendLaunch {
     int op = PEND_OP_ROLLOUT;
     int env_id = 0, precision = 0;
+    int ode_method = 0;  // enum emei_ode_method (CartPole only)
     void* state = nullptr;
     int32_t* steps = nullptr;
     uint32_t* episode = nullptr;

@@ -180,6 +180,76 @@ struct CartPole {
 };
 
 // =============================================================================================
+// CartPole integrated by ODE_approximation(method="rk4") — base_control.py:165-170.  The reference's step() never reaches
+// this branch (:73 passes no `method`); a handle selects it explicitly (emei_config.ode_method = EMEI_ODE_RK4).  Everything
+// but the substep is CartPole's.  A separate Env type (and translation unit) on purpose: the Euler kernels are the benchmarked
+// ones and sit on an instruction-cache edge (pendulum_kernels.h: EMEI_GROUP_UNROLL) — not one instruction of theirs changes.
+//
+// The promotion chain is the reference's own (NumPy 2; pinned bit for bit by oracle/emei_oracle.c:cp_ode_rk4 against
+// tests/golden/cartpole_rk4_golden.npz): _dsdt evaluates in float64 and returns float32; `dt * k` and `/ 2` are float32 (dt a
+// weak Python scalar), the stage state `y + dt * k / 2` a float64 sum; `(k1 + 2 k2 + 2 k3 + k4) * dt / 6` a chain of float32
+// roundings added to the float64 accumulator.  x itself enters no derivative (cartpole.py:48-60), so the stage states carry
+// x_dot, theta, theta_dot only.
+// =============================================================================================
+template <int VARIANT, typename R>
+struct CartPoleRK4 : CartPole<VARIANT, R> {
+    using Base = CartPole<VARIANT, R>;
+    using real = R;
+    using Carry = typename Base::Carry;
+    using Params = typename Base::Params;
+    using Action = R;
+
+    // (x_acc, theta_acc) of cartpole.py:48-60 at (theta_dot, sin theta, cos theta), rounded to float32 (:60); the same
+    // arithmetic as CartPole::substep (constants folded, refined reciprocal: a few ulp of float64 from the reference's
+    // expression order, far below the float32 rounding that follows)
+    __device__ __forceinline__ static void accel32(R theta_dot, R sn, R cs, R force_over_m, float& x_acc, float& theta_acc) {
+        const R A = R(0.1 * 0.5 / 1.1), B = R(0.5 * 0.1 / 1.1), L43 = R(0.5 * 4.0 / 3.0), gravity = R(9.8);
+        const R temp = fma_r(A * (theta_dot * theta_dot), sn, force_over_m);
+        const R num = fma_r(gravity, sn, -(cs * temp));
+        const R den = fma_r(cs * cs, -B, L43);
+        const R ta = div_r(num, den);
+        const R xa = fma_r(-(A * ta), cs, temp);
+        x_acc = (float)xa, theta_acc = (float)ta;
+    }
+
+    __device__ __forceinline__ static void substep(R s[4], Carry& c, R force_over_m, const Params& p) {
+        const float dt = p.dt32;
+        // k = (x_dot, x_acc, theta_dot, theta_acc) as float32; k1 at the current state (its sin / cos is the carry)
+        float kxd[4], kxa[4], ktd[4], kta[4];
+        kxd[0] = c.xd32, ktd[0] = c.td32;
+        accel32(s[3], c.sn, c.cs, force_over_m, kxa[0], kta[0]);
+#pragma unroll
+        for (int st = 1; st < 4; ++st) {
+            // y + dt * k / 2 (stages 2, 3) or y + dt * k (stage 4): float32 product, float32 halving, float64 sum
+            const float hxa = __fmul_rn(dt, kxa[st - 1]), htd = __fmul_rn(dt, ktd[st - 1]), hta = __fmul_rn(dt, kta[st - 1]);
+            const float half = st < 3 ? 0.5f : 1.0f;  // x / 2 == x * 0.5f exactly, for every float
+            const R xd = s[1] + (R)__fmul_rn(hxa, half), th = s[2] + (R)__fmul_rn(htd, half), td = s[3] + (R)__fmul_rn(hta, half);
+            R sn, cs;
+            sincos_ctx(c.trig, th, sn, cs);
+            kxd[st] = (float)xd, ktd[st] = (float)td;
+            accel32(td, sn, cs, force_over_m, kxa[st], kta[st]);
+        }
+        // y += (k1 + 2 k2 + 2 k3 + k4) * dt / 6: float32 throughout, a true division by 6
+        auto comb = [&](const float (&k)[4]) __attribute__((always_inline)) {
+            const float a = __fadd_rn(k[0], __fmul_rn(2.0f, k[1]));
+            const float b = __fadd_rn(a, __fmul_rn(2.0f, k[2]));
+            return __fdiv_rn(__fmul_rn(__fadd_rn(b, k[3]), dt), 6.0f);
+        };
+        s[0] += (R)comb(kxd), s[1] += (R)comb(kxa), s[2] += (R)comb(ktd), s[3] += (R)comb(kta);
+        c.xd32 = (float)s[1], c.td32 = (float)s[3];
+        sincos_ctx(c.trig, s[2], c.sn, c.cs);
+    }
+
+    __device__ __forceinline__ static void step(R s[4], Carry& c, Action force, const Params& p, int freq_rate,
+                                                R o[4], R& rew, bool& term) {
+        for (int k = 0; k < freq_rate; ++k) substep(s, c, force, p);
+        Base::obs_of(s, o);
+        rew = Base::reward(o, c, p);
+        term = Base::terminal(o, c, p);
+    }
+};
+
+// =============================================================================================
 // InvertedPendulum — emei/envs/mujoco/inverted_pendulum.py on emei/envs/mujoco/mujoco_env.py
 // VARIANT 0 ReboundBalancing, 1 BoundaryBalancing, 2 ReboundSwingUp, 3 BoundarySwingUp.
 // state = (x, theta_unwrapped, v, omega) = (qpos, qvel); obs wraps theta (:45-49).

@@ -72,12 +72,16 @@ class Engine:
 
     def __init__(self, env_name, n_envs, freq_rate=1, real_time_scale=0.02, precision="ref", max_episode_steps=0,
                  device=None, seed=0, env_index_offset=0, init_noise=0.0, integrator="euler", obs_noise=0.0,
-                 noise_layout="iid", env_params=None, solver="newton"):
+                 noise_layout="iid", env_params=None, solver="newton", ode_method="euler", rollout_chunk_steps=0):
         """init_noise / obs_noise: one sigma, a (qpos sigma, qvel sigma) pair, or one sigma per state coordinate
         (qpos entries then qvel entries): the reduced forms of mujoco_env.py:218-227.
         env_params: {name: value} overriding reward / health constructor defaults (names: _lib.ENV_PARAMS).
         solver: constraint solver of HalfCheetah / Hopper: "newton" (MuJoCo's formulation, converged; the default) or
-        "sweep1" (round 1's single Gauss-Seidel sweep)."""
+        "sweep1" (round 1's single Gauss-Seidel sweep).
+        ode_method: CartPole only — the `method` of ODE_approximation: "euler" is what the reference's step() always runs
+        (base_control.py:73), "rk4" its other branch (:165-170), an explicit opt-in.
+        rollout_chunk_steps: rollouts of the one-wave-per-SIMD bodies as (64 envs) x (k steps) work items: 0 = automatic,
+        -1 = off, k > 0 = k steps per item (emei_hip.h: emei_config.rollout_chunk_steps); results do not depend on it."""
         if env_name not in L.ENV_IDS:
             raise ValueError(f"unknown env {env_name!r}; known: {sorted(L.ENV_IDS)}")
         if integrator not in L.INTEGRATORS:
@@ -93,13 +97,17 @@ class Engine:
         if solver not in L.SOLVERS:
             raise ValueError(f"solver {solver!r}; known: {sorted(L.SOLVERS)}")
         self.solver = solver
+        if ode_method not in L.ODE_METHODS:
+            raise NotImplementedError(f"approximation method `{ode_method}` is not suppoerted yet.")  # base_control.py:171-172
+        self.ode_method = ode_method
         sig = C.c_float * L.MAX_STATE_DIM
         cfg = L.EmeiConfig(C.sizeof(L.EmeiConfig), L.ENV_IDS[env_name], self.n_envs, self.freq_rate, self.precision,
                            self.real_time_scale, int(max_episode_steps), self.device.index, int(seed),
                            int(env_index_offset), 0.0, L.INTEGRATORS[integrator],
                            {"iid": L.NOISE_IID, "shared": L.NOISE_SHARED}[noise_layout],
                            sig(*_sigmas(init_noise, self.state_dim)), sig(*_sigmas(obs_noise, self.state_dim)),
-                           *((lambda m, a: (m, L.SOLVERS[solver], a))(*L.pack_env_params(env_params))))
+                           *((lambda m, a: (m, L.SOLVERS[solver], a))(*L.pack_env_params(env_params))),
+                           L.ODE_METHODS[ode_method], int(rollout_chunk_steps))
         self._h = C.c_void_p()
         self._host_io = None
         with torch.cuda.device(self.device):
@@ -109,6 +117,14 @@ class Engine:
         if getattr(self, "_h", None) is not None and self._h:
             L.lib().emei_destroy(self._h)
             self._h = None
+        # the pre-bound emei_step_host call holds the raw handle: it must not outlive it (a step_host() after
+        # close() passed a dangling emei_env* into the library)
+        self._host_io = None
+        self._host_bufs = None
+
+    def _live(self):
+        if not self._h:
+            raise L.EmeiHipError("this Engine has been closed")
 
     def __del__(self):
         try:
@@ -130,6 +146,13 @@ class Engine:
         """Newton solves of this engine's rollouts that ended at the iteration cap without converging (must stay 0)."""
         out = torch.zeros(1, dtype=torch.int64, device=self.device)
         L.check(L.lib().emei_get_solver_cap_hits(self._h, _ptr(out), _stream()))
+        return int(out.item())
+
+    @_on_device
+    def rollout_faults(self):
+        """Work items of this engine's chunked body rollouts that gave up waiting for their predecessor (must stay 0)."""
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        L.check(L.lib().emei_get_rollout_faults(self._h, _ptr(out), _stream()))
         return int(out.item())
 
     def last_kernel(self):
@@ -214,6 +237,7 @@ class Engine:
         views of the pinned buffers (valid until the next call)."""
         io = self._host_io
         if io is None:
+            self._live()
             io = self._host_io = self._make_host_io()
         act_np, obs64_np, obs32_np, rew_np, done_np, call, flag_auto = io
         act_np[...] = action
@@ -355,12 +379,14 @@ def batch_terminal(env_name, obs, env_params=None):
     return out.bool()
 
 
-def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref", integrator="euler"):
+def batch_next_obs(env_name, obs, actions, real_time_scale=0.02, freq_rate=1, precision="ref", integrator="euler", ode_method="euler"):
+    """ode_method: classic control only (ODE_approximation's `method`, base_control.py:133-173)"""
     obs = _rows(obs, obs.device if isinstance(obs, torch.Tensor) else "cuda")
     actions = actions.to(obs.device).contiguous()
     out = torch.empty_like(obs)
     with torch.cuda.device(obs.device):
         L.check(L.lib().emei_next_obs_io(L.ENV_IDS[env_name], obs.shape[0], _io(obs), _ptr(obs), _ptr(actions),
                                          _ACT_DTYPES[actions.dtype], float(real_time_scale), int(freq_rate),
-                                         {"ref": 0, "f32": 1}[precision], L.INTEGRATORS[integrator], _ptr(out), _stream()))
+                                         {"ref": 0, "f32": 1}[precision],
+                                         L.INTEGRATORS[integrator] | (L.NEXT_OBS_ODE_RK4 if L.ODE_METHODS[ode_method] else 0), _ptr(out), _stream()))
     return out

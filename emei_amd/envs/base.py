@@ -29,13 +29,15 @@ def _is_tensor(x):
 class HipEnv(EmeiEnv):
     ENGINE_NAME = None  # key of emei_amd._lib.ENV_IDS
     ENGINE_INTEGRATOR = None  # set per instance by the MuJoCo-backed envs; classic control ignores the kwarg
+    ODE_METHOD = "euler"  # set per instance by the classic-control envs (`ode_method=`): ODE_approximation's `method`
     metadata = {"render_modes": [], "render_fps": 50}
 
     def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler",
                  num_envs: int = 1, precision: str = "ref", device: Optional[int] = None,
                  max_episode_steps: Optional[int] = None, auto_reset: bool = False, init_noise=0.0,
                  env_index_offset: int = 0, obs_noise=0.0, noise_layout: Optional[str] = None,
-                 render_mode: Optional[str] = None, engine_env_params: Optional[dict] = None, solver: str = "newton"):
+                 render_mode: Optional[str] = None, engine_env_params: Optional[dict] = None, solver: str = "newton",
+                 rollout_chunk_steps: int = 0):
         if render_mode is not None:
             # base_control.py:15,21 / mujoco_env.py:33 accept "human" / "rgb_array"; pygame and the MuJoCo viewer
             # are outside the env-step path
@@ -52,6 +54,7 @@ class HipEnv(EmeiEnv):
         self._init_noise = init_noise
         self._engine_env_params = dict(engine_env_params or {})  # non-default reward / health parameters (_lib.ENV_PARAMS)
         self._obs_noise = obs_noise
+        self._rollout_chunk_steps = int(rollout_chunk_steps)  # Engine: work items of the one-wave-per-SIMD bodies' rollouts
         self._solver = solver  # constraint solver of the multi-constraint bodies (HalfCheetah, Hopper): "newton" | "sweep1"
         # the reference only works for B = 1, where its row slicing shares one draw over all of qpos and
         # one over all of qvel (mujoco_env.py:243-244); the vectorised form draws per coordinate
@@ -99,7 +102,8 @@ class HipEnv(EmeiEnv):
                                   max_episode_steps=self.max_episode_steps, device=self.device_index,
                                   env_index_offset=self._env_index_offset, init_noise=self._init_noise,
                                   integrator=self.ENGINE_INTEGRATOR or "euler", obs_noise=self._obs_noise,
-                                  noise_layout=self._noise_layout, env_params=self._engine_env_params, solver=self._solver)
+                                  noise_layout=self._noise_layout, env_params=self._engine_env_params, solver=self._solver,
+                                  ode_method=self.ODE_METHOD, rollout_chunk_steps=self._rollout_chunk_steps)
         return self._engine
 
     def _host_init_state(self, batch_size) -> np.ndarray:
@@ -254,7 +258,7 @@ class HipEnv(EmeiEnv):
         else:
             a = a.to(torch.float32).reshape(o.shape[0], -1)
         nxt = E.batch_next_obs(self.ENGINE_NAME, o, a.contiguous(), self.real_time_scale, self.freq_rate, self.precision,
-                               self.ENGINE_INTEGRATOR or "euler")
+                               self.ENGINE_INTEGRATOR or "euler", self.ODE_METHOD)
         if isinstance(obs, torch.Tensor):
             return nxt
         return nxt.cpu().numpy().astype(np.float64)

@@ -11,7 +11,15 @@ class BaseCartPoleEnv(HipEnv):
     """cartpole.py:16-60: constants, spaces.  Abstract like the reference: reset() raises
     NotImplementedError because get_batch_init_state is not defined (test_cartpole.py:4-11)."""
 
-    def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler", **kwargs):
+    def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler", ode_method: str = "euler",
+                 **kwargs):
+        """integrator: accepted and IGNORED, as in the reference (base_control.py:73 calls ODE_approximation without `method`,
+        so every classic-control env steps with forward Euler whatever this says).
+        ode_method (not a reference kwarg): the `method` argument of ODE_approximation itself — "rk4" runs the function's other
+        branch (base_control.py:165-170, float32 k-stages) on the device; an explicit opt-in, "euler" = what step() does."""
+        if ode_method not in ("euler", "rk4"):
+            raise NotImplementedError("approximation method `{}` is not suppoerted yet.".format(ode_method))  # base_control.py:172
+        self.ODE_METHOD = ode_method
         super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator, **kwargs)
         self.gravity = 9.8
         self.mass_cart = 1.0
@@ -66,7 +74,7 @@ class CartPoleSwingUpEnv(BaseCartPoleEnv):
     ENGINE_NAME = "CartPoleSwingUp"
 
     def __init__(self, freq_rate: int = 1, real_time_scale: float = 0.02, integrator: str = "euler", **kwargs):
-        super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator, **kwargs)
+        super().__init__(freq_rate=freq_rate, real_time_scale=real_time_scale, integrator=integrator, **kwargs)  # ode_method: kwargs
         self.x_threshold = 5
 
     def _host_init_state(self, batch_size):

@@ -173,7 +173,7 @@ class ShardedRollout:
 
     def __init__(self, env, envs_per_rank, horizon, freq_rate=1, real_time_scale=0.02, precision="ref", rank=0,
                  world=1, device=0, seed=0, init_noise=None, integrator="euler", gather="final", chunk=None,
-                 force_exchange=False, solver="newton", exchange_algo="collective"):
+                 force_exchange=False, solver="newton", exchange_algo="collective", rollout_chunk_steps=0):
         from .engine import Engine
 
         self.env, self.n, self.horizon, self.rank, self.world = env, int(envs_per_rank), int(horizon), rank, world
@@ -191,7 +191,8 @@ class ShardedRollout:
             init_noise = 0.1 if env == "HalfCheetahRunning" else 5e-3
         self.engine = Engine(env, self.n, freq_rate=freq_rate, real_time_scale=real_time_scale, precision=precision,
                              max_episode_steps=self.MAX_EPISODE_STEPS.get(env, 1000), device=device, seed=seed,
-                             env_index_offset=self.lo, init_noise=init_noise, integrator=integrator, solver=solver)
+                             env_index_offset=self.lo, init_noise=init_noise, integrator=integrator, solver=solver,
+                             rollout_chunk_steps=rollout_chunk_steps)
         self.device = self.engine.device
         self.obs_dim, self.act_dim = self.engine.obs_dim, self.engine.act_dim
         self.seed = seed

@@ -26,8 +26,12 @@ extern "C" {
  * emei_set_seed, emei_last_rollout_kernel, emei_config.solver (the former reserved0; reserved words MUST be zero).
  * 3: the *_io stateless entry points (float64 observations), emei_freeze / emei_unfreeze snapshot the reset key,
  *    emei_model_constants, emei_get_solver_cap_hits.
- * 4: emei_model_invweights. */
-#define EMEI_ABI_VERSION 5
+ * 4: emei_model_invweights.
+ * 5: emei_step_host (page-locked host values in and out; for n_envs == 1 of the 4-state family one launch whose last store is a
+ *    completion word the library polls).
+ * 6: emei_config.ode_method (classic control's ODE_approximation(method="rk4"), opt-in) and emei_config.rollout_chunk_steps
+ *    (struct_size 408; a 400-byte caller gets euler / automatic), emei_get_rollout_faults, EMEI_NEXT_OBS_ODE_RK4. */
+#define EMEI_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -65,6 +69,13 @@ enum emei_precision { EMEI_PRECISION_REF = 0, EMEI_PRECISION_F32 = 1 };
  * SEMI_IMPLICIT  : MuJoCo Euler as it is: v' = v + dt*qacc, q += dt*v'
  * RK4            : MuJoCo's 4-stage Runge-Kutta (mjINT_RK4): full forward dynamics at every stage */
 enum emei_integrator { EMEI_INTEG_EULER = 0, EMEI_INTEG_SEMI_IMPLICIT = 1, EMEI_INTEG_RK4 = 2 };
+
+/* `method` of ODE_approximation for the classic-control envs (base_control.py:133-173).  The reference's step() never
+ * passes it (:73), so every classic-control env is integrated with EULER whatever its `integrator` kwarg says — that stays the
+ * default.  RK4 is the function's other branch (:165-170), reachable only by calling ODE_approximation directly; selecting it
+ * here is an explicit opt-in and reproduces that branch's float32 / float64 promotion chain (k stages are float32 arrays,
+ * the stage states float64).  Ignored by the MuJoCo-backed bodies (their switch is `integrator`). */
+enum emei_ode_method { EMEI_ODE_EULER = 0, EMEI_ODE_RK4 = 1 };
 
 /* How Gaussian init / observation noise is laid out over the coordinates of one env.
  * IID      : an independent draw per coordinate (the evident intent of additive_gaussian_noise)
@@ -145,6 +156,19 @@ typedef struct emei_config {
     uint32_t env_param_mask;
     uint32_t solver;            /* enum emei_solver (this field was `reserved0`, always 0, before) */
     double env_params[EMEI_MAX_ENV_PARAMS];
+    /* -- from struct_size 408 (ABI 6) --------------------------------------------------------------------------------- */
+    int32_t ode_method;          /* enum emei_ode_method: CartPole only (base_control.py:165-170); 0 = what step() runs */
+    /* emei_rollout of the bodies that run one-wave blocks (HalfCheetah, Hopper with the NEWTON solver, the double pendulum):
+     * the launch is cut into work items of (64 envs) x (a chunk of steps), handed out chunk-major by an atomic ticket to
+     * persistent one-wave workers, so that a SIMD that finishes early takes the next item instead of idling until the slowest
+     * wave of the launch ends; an env's state travels between its items through the handle's state arrays, results are
+     * bit-identical to the one-piece launch.
+     *   0 = automatic: on when the shard has more waves than the device holds at once, with the guided schedule (each chunk
+     *       a quarter of the steps that remain: long items first, one-step items last)
+     *  -1 = off (one-piece launches)
+     *   k > 0 = k steps per item
+     *  -(100 + g), g = 1 .. 6 = the guided schedule with 1 / 2^g of the remaining steps per chunk (tuning) */
+    int32_t rollout_chunk_steps;
 } emei_config;
 #define EMEI_CONFIG_SIZE_V1 64u
 
@@ -214,6 +238,12 @@ EMEI_API int emei_unfreeze(emei_env* h, void* stream);
  * (tests/test_gpu_parity_sweeps.py, tests/test_gpu_long_horizon.py assert 0).  Always 0 for the other envs and the SWEEP1 solver. */
 EMEI_API int emei_get_solver_cap_hits(emei_env* h, uint64_t* count_out, void* stream);
 
+/* Work items of this handle's chunked body rollouts (emei_config.rollout_chunk_steps) that gave up waiting for the item that
+ * precedes them on the same envs (a bounded wait: 2 s of the device's 100 MHz counter) and were skipped, since emei_create:
+ * count_out [1] uint64 (device-accessible).  Must stay 0 — an item's predecessor has always started before it (tickets are
+ * handed out in start order); a non-zero count means a rollout's outputs are incomplete. */
+EMEI_API int emei_get_rollout_faults(emei_env* h, uint64_t* count_out, void* stream);
+
 /* Re-key the device reset generator without touching the state: the seed of Env.reset(seed=) reaches the
  * handle also when the initial state itself is drawn on the host and uploaded with emei_set_state
  * (base_control.py:38-47: gym seeds np_random, every later auto-reset episode must depend on it too). */
@@ -258,7 +288,9 @@ enum emei_kernel_id {
     EMEI_KERNEL_PEND_GENERIC_FULL = 3, /* pend_rollout_kernel<Env, ActT, true>: ragged n, short T or unaligned buffers */
     EMEI_KERNEL_PEND_GENERIC = 4,      /* pend_rollout_kernel<Env, ActT, false>: some output pointer is NULL */
     EMEI_KERNEL_BODY = 5,              /* body_rollout_kernel<Body, false> (euler / semi-implicit euler) */
-    EMEI_KERNEL_BODY_RK4 = 6           /* body_rollout_kernel<Body, true> */
+    EMEI_KERNEL_BODY_RK4 = 6,          /* body_rollout_kernel<Body, true> */
+    EMEI_KERNEL_BODY_CHUNKED = 7,      /* body_rollout_kernel<Body, false> as (64 envs) x (chunk of steps) work items (rollout_chunk_steps) */
+    EMEI_KERNEL_BODY_RK4_CHUNKED = 8   /* body_rollout_kernel<Body, true> likewise */
 };
 EMEI_API int emei_last_rollout_kernel(emei_env* h);
 
@@ -325,7 +357,9 @@ EMEI_API int emei_next_obs_ex(int env_id, int64_t n, const float* obs, const voi
                      float* next_obs_out, void* stream);
 
 /* emei_next_obs_ex on the caller's dtype: obs and next_obs_out are [n, obs_dim] of io_dtype (float64 observations enter the
- * float64 state unrounded); actions as in emei_step. */
+ * float64 state unrounded); actions as in emei_step.  `integrator` may carry EMEI_NEXT_OBS_ODE_RK4 for the classic-control
+ * envs (enum emei_ode_method RK4: ODE_approximation(method="rk4"), base_control.py:165-170); ignored by the other envs. */
+#define EMEI_NEXT_OBS_ODE_RK4 0x100
 EMEI_API int emei_next_obs_io(int env_id, int64_t n, int io_dtype, const void* obs, const void* actions, int action_dtype,
                      double real_time_scale, int32_t freq_rate, int32_t precision, int32_t integrator,
                      void* next_obs_out, void* stream);

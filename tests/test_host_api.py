@@ -121,7 +121,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert (od.value, ad.value, sd.value) == (18, 6, 18)
     assert lib.emei_env_dims(99, None, None, None) == _lib.ERR_INVALID
     # the struct layout of the binding is checked by the library itself
-    cfg = _lib.EmeiConfig(C.sizeof(_lib.EmeiConfig) - 8, 0, 16, 1, 0, 0.02, 0, 0, 0, 0, 0.0)
+    cfg = _lib.EmeiConfig(C.sizeof(_lib.EmeiConfig) - 4, 0, 16, 1, 0, 0.02, 0, 0, 0, 0, 0.0)  # (- 8 is the ABI-5 size: accepted)
     h = C.c_void_p()
     assert lib.emei_create(C.byref(cfg), C.byref(h)) == _lib.ERR_INVALID
     assert b"emei_config size" in lib.emei_last_error()
@@ -158,6 +158,10 @@ def test_create_rejects_bad_configs_before_touching_a_device():
     assert create(real_time_scale=0.0)[0] == _lib.ERR_INVALID
     assert create(real_time_scale=float("nan"))[0] == _lib.ERR_INVALID
     assert create(noise_layout=2)[0] == _lib.ERR_INVALID
+    assert create(ode_method=2)[0] == _lib.ERR_UNSUPPORTED  # base_control.py:171-172 raises NotImplementedError
+    rc, msg = create(ode_method=_lib.ODE_METHODS["rk4"])  # ODE_approximation is classic control's; the bodies switch on `integrator`
+    assert rc == _lib.ERR_INVALID and "ode_method" in msg
+    assert create(rollout_chunk_steps=-2)[0] == _lib.ERR_INVALID
     assert create(env_id=99)[0] == _lib.ERR_INVALID
     assert create(env_param_mask=1 << 8)[0] == _lib.ERR_INVALID
     assert create(env_param_mask=1 << 2)[0] == _lib.ERR_INVALID  # HalfCheetah has only the two reward weights
