@@ -234,7 +234,8 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (cfg->ode_method != EMEI_ODE_EULER && cfg->env_id != EMEI_CARTPOLE_SWINGUP && cfg->env_id != EMEI_CARTPOLE_BALANCING)
         return fail(EMEI_ERR_INVALID, "emei_create: ode_method is ODE_approximation's switch (classic control); env_id %d is integrated "
                     "according to `integrator`", cfg->env_id);
-    if (cfg->rollout_chunk_steps < -1 && (cfg->rollout_chunk_steps > -101 || cfg->rollout_chunk_steps < -106)) return fail(EMEI_ERR_INVALID, "emei_create: rollout_chunk_steps=%d", cfg->rollout_chunk_steps);
+    if (cfg->rollout_chunk_steps < -1 && (cfg->rollout_chunk_steps > -101 || cfg->rollout_chunk_steps < -1506 ||
+                                          -cfg->rollout_chunk_steps % 100 < 1 || -cfg->rollout_chunk_steps % 100 > 6)) return fail(EMEI_ERR_INVALID, "emei_create: rollout_chunk_steps=%d", cfg->rollout_chunk_steps);
     if (cfg->solver != EMEI_SOLVER_NEWTON && cfg->solver != EMEI_SOLVER_SWEEP1) return fail(EMEI_ERR_INVALID, "emei_create: solver=%u", cfg->solver);
     if (cfg->env_param_mask >> EMEI_MAX_ENV_PARAMS) return fail(EMEI_ERR_INVALID, "emei_create: env_param_mask=0x%x", cfg->env_param_mask);
     if (cfg->env_param_mask != 0 && cfg->env_id != EMEI_HALFCHEETAH_RUNNING && cfg->env_id != EMEI_HOPPER_RUNNING)

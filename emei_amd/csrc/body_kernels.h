@@ -244,27 +244,30 @@ struct BodyArgs {
 // 101 B x chunk_steps of outputs.
 // Results are bit-identical to the one-piece launch: an item runs the same per-step code from the same state
 // (tests/test_gpu_shapes.py: a fused rollout, its chunks and its single steps agree bit for bit).
+constexpr int kGuidedShift = 1, kGuidedMin = 3;  // the automatic schedule: half of what remains, at least 3 steps (the sweep in profiles/r05_cheetah_tail.txt)
 struct WorkQueue {
     // word offsets; [kProgress + w] = chunks of env-wave w that are done.  The fault count is sticky, the words behind it are
     // zeroed (one memset) in front of every chunked launch
     enum { kFaults = 0, kTicket = 1, kProgress = 2 };
     static constexpr unsigned long long kWaitTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
-    // Step range [t_begin, t_end) of chunk `chunk`.  chunk_steps > 0: fixed length.  chunk_steps = -g < 0: the GUIDED schedule —
-    // every chunk takes 1 / 2^g of the steps that remain (at least one): long items first, where a worker's finishing time does
-    // not matter and the per-item cost (ticket, state round trip, release: ~4 us) is paid rarely, short items last, where
-    // the launch ends with the slowest worker's LAST item (100 steps, g = 2: 25 19 14 11 8 6 5 3 3 2 1 1 1 1 = 14 items
-    // instead of the 20 of a fixed length 5, and a last item of one step).  Host and device run the same recurrence.
+    // Step range [t_begin, t_end) of chunk `chunk`.  chunk_steps > 0: fixed length.  chunk_steps = -((m << 4) | g): the GUIDED
+    // schedule — every chunk takes 1 / 2^g of the steps that remain, at least m: long items first, where a worker's finishing time
+    // does not matter and the per-item cost (ticket, state round trip, release: ~3 us) is paid rarely, short items last, where
+    // the launch ends with the slowest worker's LAST item (100 steps, g = 1, m = 3: 50 25 13 6 3 3 = 6 items per wave instead of
+    // the 20 of a fixed length 5).  Items of one or two steps at the very end cost more than they save: a slow wave's step takes
+    // longer than a row of such items takes to hand out, so its items queue up behind each other (waiting workers).  Host and
+    // device run the same recurrence.
     __host__ __device__ static void item_steps(int n_steps, int chunk_steps, uint32_t chunk, int& t_begin, int& t_end) {
         if (chunk_steps > 0) {
             t_begin = (int)chunk * chunk_steps;
             t_end = t_begin + chunk_steps < n_steps ? t_begin + chunk_steps : n_steps;
             return;
         }
-        const int g = -chunk_steps;
+        const int g = (-chunk_steps) & 15, min_len = (-chunk_steps) >> 4;  // encoded by launch_body: (shortest item << 4) | g
         int t = 0, len = 0;
         for (uint32_t c = 0;; ++c) {
             len = (n_steps - t + (1 << g) - 1) >> g;
-            len = len < 1 ? 1 : len;
+            len = len < min_len ? min_len : len;
             if (c == chunk) break;
             t += len;
         }
@@ -678,8 +681,9 @@ static int launch_body(const BodyLaunch& L) {
                 // with a quarter of the remaining steps per item.  emei_config encodes: k > 0 fixed length, -1 off, and — for
                 // experiments — -(100 + g): the guided schedule with 1 / 2^g
                 int cs = L.chunk_steps;
-                if (cs == 0) cs = (L.resident_waves > 0 && (int64_t)rgrid.x > L.resident_waves) ? -2 : 0;
-                else if (cs <= -100) cs = -min(-cs - 100, 6);
+                // (device encoding of a guided schedule: -((shortest item << 4) | g))
+                if (cs == 0) cs = (L.resident_waves > 0 && (int64_t)rgrid.x > L.resident_waves) ? -((kGuidedMin << 4) | kGuidedShift) : 0;
+                else if (cs <= -100) cs = -(((-cs / 100) << 4) | max(1, min(-cs % 100, 6)));  // -(100 m + g): shortest item m, 1 / 2^g
                 else if (cs < 0) cs = 0;
                 const unsigned n_chunks = cs != 0 ? WorkQueue::count_chunks(L.n_steps, cs) : 1u;
                 if (L.work && n_chunks > 1 && (uint64_t)rgrid.x * n_chunks < (1ull << 31)) {

@@ -164,10 +164,10 @@ typedef struct emei_config {
      * wave of the launch ends; an env's state travels between its items through the handle's state arrays, results are
      * bit-identical to the one-piece launch.
      *   0 = automatic: on when the shard has more waves than the device holds at once, with the guided schedule (each chunk
-     *       a quarter of the steps that remain: long items first, one-step items last)
+     *       half of the steps that remain, at least three: long items first, short items last)
      *  -1 = off (one-piece launches)
      *   k > 0 = k steps per item
-     *  -(100 + g), g = 1 .. 6 = the guided schedule with 1 / 2^g of the remaining steps per chunk (tuning) */
+     *  -(100 m + g), m = 1 .. 15, g = 1 .. 6 = the guided schedule with 1 / 2^g of the remaining steps per chunk, at least m (tuning) */
     int32_t rollout_chunk_steps;
 } emei_config;
 #define EMEI_CONFIG_SIZE_V1 64u

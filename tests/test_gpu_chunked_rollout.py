@@ -32,7 +32,7 @@ CASES = [
 
 @pytest.mark.parametrize("env,kw,scale", CASES, ids=[f"{c[0]}-{c[1].get('integrator', 'euler')}" for c in CASES])
 @pytest.mark.parametrize("N", [64 * 37 + 17, 64, 1])
-@pytest.mark.parametrize("chunk", [1, 5, -102])  # fixed lengths; the guided schedule (a quarter of what remains per item)
+@pytest.mark.parametrize("chunk", [1, 5, -102, -301])  # fixed lengths; guided schedules (a quarter / half of what remains per item, at least 1 / 3)
 def test_chunked_rollout_is_bit_identical(env, kw, scale, N, chunk):
     from emei_amd import _lib
 
