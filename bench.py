@@ -112,9 +112,35 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
             el = time.perf_counter() - t0
             if el > budget_s:
                 break
-        return {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, auto-reset, TimeLimit {max_steps}, "
-                          f"float32 obs / reward and uint8 done written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+        out = {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+               "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, auto-reset, TimeLimit {max_steps}, "
+                         f"float32 obs / reward and uint8 done written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+        # SURVEY 8d's other two CPU numbers.  one_core: the same C rollout on ONE thread (a 2 s sample of a 1/16 shard)
+        O.set_threads(1)
+        n1 = max(64, n // 16)
+        r1 = O.cartpole_rollout_autoreset(variant, st[:n1], acts[:, :n1], 0, None, max_steps, freq_rate, dt)
+        t0, calls1 = time.perf_counter(), 0
+        while True:
+            r1 = O.cartpole_rollout_autoreset(variant, r1["state"], acts[:, :n1], 0, None, max_steps, freq_rate, dt, r1["steps"], r1["episode"], reuse=r1)
+            calls1 += 1
+            el1 = time.perf_counter() - t0
+            if el1 > 2.0:
+                break
+        O.set_threads(cores)
+        out["one_core"] = {"value": n1 * Tc * calls1 / el1, "unit": "env-steps/s", "cores": 1,
+                           "sample": f"{calls1} fused rollouts of {Tc} steps x {n1} envs, the same C oracle on one thread, {el1:.1f} s"}
+        # reference_style: ONE env stepped the way the reference steps it — a CPython call per step, scalar math.sin / cos, float32
+        # np.array derivative, np.append, batched reward / terminal on a [1, 4] row (base_control.py:61-83; BASELINE configs[0]'s
+        # call pattern).  Build-authored (oracle/oracle.py:cartpole_reference_style_loop), bit-identical to the C oracle.
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.0:
+            O.cartpole_reference_style_loop(variant, 1000, 0, freq_rate, dt)
+            reps += 1
+        el2 = time.perf_counter() - t0
+        out["reference_style"] = {"value": 1000 * reps / el2, "unit": "env-steps/s", "cores": 1, "ms_per_1000_steps": el2 / reps * 1e3,
+                                  "sample": f"{reps} x 1000 steps of ONE {env} env in a per-step NumPy / math loop that mirrors base_control.py:61-83 "
+                                            "(the reference itself took 60.6 ms per 1000 steps in the build container, BASELINE.md)"}
+        return out
     # the MuJoCo-backed bodies: the same kind of twin — Tc env-steps per C call (blocks of envs over the OpenMP threads, no Python
     # between steps), float32 obs / reward and uint8 terminal written per env-step, no reset (as the per-step reference) —
     # step for step the per-step oracle's arithmetic (tests/test_oracle_golden.py)
@@ -145,10 +171,56 @@ def cpu_baseline(env, n, freq_rate, dt, integrator="euler", solver="newton", bud
         el = time.perf_counter() - t0
         if el > budget_s:
             break
-    return {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, {integrator}"
-                      + ("" if "Pendulum" in env else f", {solver} solver")
-                      + f", no reset, float32 obs / reward and uint8 terminal written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+    out = {"value": n * Tc * calls / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{calls} fused rollouts of {Tc} steps x {n} {env} envs (freq_rate {freq_rate}, dt {dt}, {integrator}"
+                     + ("" if "Pendulum" in env else f", {solver} solver")
+                     + f", no reset, float32 obs / reward and uint8 terminal written per env-step) with the C oracle (float64, OpenMP x{cores}), {el:.1f} s"}
+    # one_core: the same C rollout on one thread, a 2 s sample of a 1/16 shard
+    O.set_threads(1)
+    n1 = max(64, n // 16)
+    r1 = O.body_rollout(kind, variant, st[:n1], acts[:, :n1], freq_rate, dt, opt)
+    t0, calls1 = time.perf_counter(), 0
+    while True:
+        r1 = O.body_rollout(kind, variant, r1["state"], acts[:, :n1], freq_rate, dt, opt, reuse=r1)
+        calls1 += 1
+        el1 = time.perf_counter() - t0
+        if el1 > 2.0:
+            break
+    O.set_threads(cores)
+    out["one_core"] = {"value": n1 * Tc * calls1 / el1, "unit": "env-steps/s", "cores": 1,
+                       "sample": f"{calls1} fused rollouts of {Tc} steps x {n1} envs, the same C oracle on one thread, {el1:.1f} s"}
+    return out
+
+
+def rccl_summary(path, world):
+    """What RCCL reported about itself (NCCL_DEBUG=INFO of rank 0, best effort: the wording differs between versions): version,
+    ranks of the communicator, channels, and the lines that name an algorithm / protocol."""
+    import re
+
+    info = {"log": path, "nranks": None, "version": None, "channels": None, "algo_proto_lines": []}
+    try:
+        txt = open(path, errors="replace").read()
+    except OSError as e:
+        info["error"] = str(e)
+        return info
+    m = re.search(r"(?:RCCL|NCCL) version ([^\s]+)", txt)
+    info["version"] = m.group(1) if m else None
+    m = re.search(r"nranks (\d+)", txt)
+    info["nranks"] = int(m.group(1)) if m else None
+    ch = re.findall(r"(\d+) coll channels|Channel (\d+)/", txt)
+    if ch:
+        info["channels"] = max(int(a or b) for a, b in ch) + (0 if ch[0][0] else 1)
+    seen = []
+    for line in txt.splitlines():
+        if re.search(r"\b(algo|Algo|protocol|Proto|proto)\b", line) and ("AllGather" in line or "all_gather" in line.lower() or "Algo" in line):
+            short = re.sub(r"^.*?NCCL INFO ", "", line)[:160]
+            if short not in seen:
+                seen.append(short)
+        if len(seen) >= 8:
+            break
+    info["algo_proto_lines"] = seen
+    info["expected_nranks"] = world
+    return info
 
 
 def self_launch(n_gpus):
@@ -160,10 +232,14 @@ def self_launch(n_gpus):
     # Under a profiler the preloaded tool library has already initialised the GPU in THIS process, and the ranks would be
     # its grandchildren: counters attach to the wrong process and a GPU-initialised parent must not spawn a launcher on
     # this pool.  Profile a rank directly: `torchrun ... ` started first, rocprofv3 in front of each rank's `python bench.py`.
+    # Detected by the preload itself (LD_PRELOAD naming a rocprofiler library, or the variables rocprofv3 sets to force its tool
+    # in: ROCP_TOOL_LIBRARIES / ROCPROFILER_REGISTER_FORCE_LOAD) — module files and containers export other ROCPROFILER_* / ROCP_*
+    # variables (paths, register settings) with no profiler attached.  --allow-profiler-env overrides.
     preload = os.environ.get("LD_PRELOAD", "")
-    if "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ):
+    attached = "rocprof" in preload or any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+    if attached and "--allow-profiler-env" not in sys.argv:
         sys.stderr.write("bench.py: --gpus N>1 without a launcher refuses to run under a profiler preload "
-                         "(rocprofv3 must wrap each rank's process, not this launcher parent)\n")
+                         "(rocprofv3 must wrap each rank's process, not this launcher parent); --allow-profiler-env overrides\n")
         raise SystemExit(2)
     with socket.socket() as sk:  # a free rendezvous port on the loopback
         sk.bind(("127.0.0.1", 0))
@@ -214,6 +290,8 @@ def main():
                          "k > 0 = k steps per item (emei_config.rollout_chunk_steps); results do not depend on it")
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed clock-settle phase before the warm-up passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-profiler-env", action="store_true", help="self-launch N > 1 ranks even though a profiler preload is detected")
+    ap.add_argument("--no-rccl-info", action="store_true", help="do not switch on NCCL_DEBUG=INFO (N > 1, RCCL: the line reports what RCCL chose)")
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
     a = ap.parse_args()
 
@@ -235,12 +313,17 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_log = None
     backend = "none (1 rank)"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("EMEI_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl" and not a.no_rccl_info and "NCCL_DEBUG" not in os.environ:
+            # what RCCL chose (ranks, channels, algorithm / protocol of the all-gather) goes into the line: its INFO log, per rank, to a file
+            rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"emei_bench_rccl_{os.getpid()}_r{rank}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,ENV,TUNING,COLL", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -334,6 +417,10 @@ def main():
             traffic, valu = prof.get("bytes_per_launch"), prof.get("valu_insts_per_launch")
         except Exception:
             prof = {}
+    # the copied counters describe the kernel the profile was taken on: flag the line when this run's kernel no longer
+    # runs as long as that one did (> 10 %: a kernel changed without tools/profile_all.sh, or a very different box)
+    prof_us = prof.get("rocprof_kernel_avg_us")
+    profile_stale = bool(prof_us) and abs(kernel_ms * 1e3 - prof_us) > 0.10 * prof_us
 
     out = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
@@ -352,6 +439,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (f"{prof.get('profile', 'profiles/')} via profiles/traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE "
                                         "passes of this command, collected separately, NOT measured in this run") if traffic else None,
+                     "profile_stale": profile_stale, "profile_kernel_avg_us": prof_us,
                      "kernel": sr.kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bpes,
                      "algorithmic_bytes_per_launch": bpes * N * T_launch},
     }
@@ -425,6 +513,40 @@ def main():
             out["value_final_gather"] = {"value": total_env_steps / float(tf.item()), "unit": "env-steps/s",
                                          "ms_per_step": float(tf.item()) / a.steps * 1e3, "gather": "final",
                                          "what": "the same job, same run, exchanging only the last [n, obs_dim] observation of each pass"}
+            sf.engine.close()
+            del sf
+        # ... and the same job with the OTHER form of the exchange (`--exchange direct`: 1-hop point-to-point transfers to and from
+        # every peer, the shape of the xGMI mesh; or the collective when direct is the run's own), same gather mode, same barrier /
+        # max-over-ranks rule: one 8-GPU run answers which of the two the node prefers
+        other = "direct" if a.exchange == "collective" else "collective"
+        so = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
+                            world=world, device=local_rank, seed=0, integrator=a.integrator or w.get("integrator", "euler"),
+                            gather=gather, chunk=chunk, solver=a.solver, exchange_algo=other, rollout_chunk_steps=a.rollout_chunk_steps)
+        so.make_synthetic_inputs()
+        for _ in range(max(a.warmup, 2)):
+            so.run_pass()
+        so.wait_gathers()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        to = time.perf_counter()
+        for _ in range(a.steps):
+            so.run_pass()
+        so.wait_gathers()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        to = torch.tensor([time.perf_counter() - to], dtype=torch.float64, device="cuda")
+        dist.all_reduce(to, op=dist.ReduceOp.MAX)
+        gbo = so.gathered_bytes_per_pass
+        out["value_direct_exchange" if other == "direct" else "value_collective_exchange"] = {
+            "value": total_env_steps / float(to.item()), "unit": "env-steps/s", "ms_per_step": float(to.item()) / a.steps * 1e3,
+            "exchange": other, "gather": gather, "xgmi_inbound_gbs": gbo * a.steps / float(to.item()) / 1e9,
+            "what": f"the same job, same run, same gather mode, the observation return as {'batched point-to-point transfers (sharding._allgather_direct)' if other == 'direct' else 'the backend all-gather'}"}
+        so.engine.close()
+        del so
+        if rccl_log:
+            out["rccl"] = rccl_summary(rccl_log, world)
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

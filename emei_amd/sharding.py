@@ -79,13 +79,17 @@ class ObsExchange:
     """Double-buffered all-gather of observation blocks, overlapped with the producer's next launches.
 
     A block ([rows, n, obs_dim], written on the launch stream into output slot `slot`) is all-gathered on a
-    dedicated stream into one of two rank-major receive buffers ([world, rows, n, obs_dim]).  Three hazards are
+    dedicated stream into one of two rank-major receive buffers ([world, rows, n, obs_dim]).  Four hazards are
     ordered with events (device tensors; on CPU tensors — the gloo tests — every call is synchronous):
-      ready       launch stream -> comm stream : the producer has written the block
-      done[slot]  comm stream -> launch stream : the gather has READ the block; `fence(slot)` makes the launch
-                                                 stream wait for it before the slot is overwritten
-      receive buffers alternate; gathers are serialised on the comm stream, so buffer b is free again when the
-      gather two collectives later starts (a consumer reads it in between)"""
+      ready        launch stream -> comm stream : the producer has written the block
+      done[slot]   comm stream -> launch stream : the gather has READ the block; `fence(slot)` makes the launch
+                                                  stream wait for it before the slot is overwritten
+      filled[b]    comm stream -> consumer      : the gather has WRITTEN receive buffer b; `acquire(buf)` / `reading(buf)`
+                                                  make the consumer's stream wait for it
+      released[b]  consumer -> comm stream      : the consumer has finished with buffer b; the NEXT gather into b (two
+                                                  collectives later: the buffers alternate) waits for it.  A caller that reads every
+                                                  observation (zoo/util.py:54-59 is the reference's pattern) on a stream of its
+                                                  own is therefore never overwritten; a buffer nobody acquired is free at once."""
 
     def __init__(self, world, rows, n, obs_dim, n_slots, device, algo="collective"):
         if algo not in ALGOS:
@@ -96,6 +100,8 @@ class ObsExchange:
         self.gathered = [torch.empty((world, rows, n, obs_dim), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._comm = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._done = [None] * n_slots
+        self._filled = [None, None]
+        self._released = [None, None]
         self.collectives = 0
 
     def fence(self, slot):
@@ -103,7 +109,8 @@ class ObsExchange:
             torch.cuda.current_stream().wait_event(self._done[slot])
 
     def exchange(self, slot, block, group=None):
-        buf = self.gathered[self.collectives & 1]
+        b = self.collectives & 1
+        buf = self.gathered[b]
         self.collectives += 1
         if not self.cuda:
             allgather_obs(block, group=group, out=buf, algo=self.algo)
@@ -112,11 +119,50 @@ class ObsExchange:
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ready)
+            if self._released[b] is not None:  # a consumer still reads what this buffer held
+                self._comm.wait_event(self._released[b])
+                self._released[b] = None
             allgather_obs(block, group=group, out=buf, algo=self.algo)
             done = torch.cuda.Event()
             done.record(self._comm)
         self._done[slot] = done
+        self._filled[b] = done
         return buf
+
+    def _index(self, buf):
+        for b in (0, 1):
+            if buf is self.gathered[b]:
+                return b
+        raise ValueError("not a receive buffer of this exchange")
+
+    def acquire(self, buf):
+        """The current stream waits until the gather that fills `buf` (a tensor `exchange` / `last` returned) is complete."""
+        b = self._index(buf)
+        if self.cuda and self._filled[b] is not None:
+            torch.cuda.current_stream().wait_event(self._filled[b])
+        return buf
+
+    def release(self, buf):
+        """The current stream is done reading `buf`: the next gather into it may start once the stream gets here."""
+        b = self._index(buf)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._released[b] = ev
+
+    def reading(self, buf):
+        """`with xchg.reading(buf): consume(buf)` on the consumer's stream = acquire, then release on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.acquire(buf)
+            try:
+                yield buf
+            finally:
+                self.release(buf)
+
+        return cm()
 
     def last(self, back=0):
         """receive buffer of the collective `back` before the most recent one (0 or 1)"""
@@ -245,10 +291,13 @@ class ShardedRollout:
             self._stage = torch.empty((1, self.n, self.obs_dim), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize()
 
-    def run_pass(self, record=False):
+    def run_pass(self, record=False, on_gathered=None):
         """The whole horizon (one launch, or one per chunk) + the batched observation return of the gather mode.
         -> the last receive buffer ([world, rows, n, obs_dim], valid once `wait_gathers` has run) or, without an
-        exchange, the local observations of the last chunk."""
+        exchange, the local observations of the last chunk.
+        on_gathered(chunk, buf): called right after the all-gather of a chunk has been ENQUEUED, with the receive buffer it fills;
+        a consumer reads it under `self.xchg.reading(buf)` on a stream of its own (the buffer is then not handed to a later
+        gather before the consumer is done — ObsExchange)."""
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -260,12 +309,16 @@ class ShardedRollout:
             last = obs
             if self.exchanging and self.gather != "final":
                 last = self.xchg.exchange(c, obs)
+                if on_gathered is not None:
+                    on_gathered(c, last)
         if record:
             e1.record()
             self._events.append((e0, e1))
         if self.exchanging and self.gather == "final":
             self._stage.copy_(last[-1:])  # one slot: fence(0) above also covers the staging buffer
             last = self.xchg.exchange(0, self._stage)
+            if on_gathered is not None:
+                on_gathered(0, last)
         return last
 
     def wait_gathers(self):

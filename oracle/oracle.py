@@ -155,6 +155,58 @@ def ip_init_f32(seed, env, episode, sigma):
     return np.array(out[:], dtype=np.float32)
 
 
+def cartpole_reference_style_loop(variant, n_steps=1000, seed=0, freq_rate=1, dt=0.02):
+    """ONE env stepped the way the reference steps it (base_control.py:61-83 -> ODE_approximation :162-164 -> _dsdt,
+    cartpole.py:48-60): a CPython call per step, scalar math.sin / math.cos, a float32 `np.array` for the derivative,
+    `np.append` for the augmented state, the batched reward / terminal functions on a [1, 4] row.  Written for bench.py's
+    `cpu_baseline.reference_style` ("reference-style single-env throughput"); same values as cartpole_step
+    (tests/test_oracle_golden.py).  -> (final state [4], rewards [n_steps], terminals [n_steps])."""
+    rng = np.random.default_rng(seed)
+    state = rng.uniform(low=-0.05, high=0.05, size=(1, 4))[0]
+    if variant == "swingup":
+        state[2] += np.pi
+    actions = np.random.default_rng(1).integers(2, size=n_steps)
+    gravity, mass_pole, length, force_mag = 9.8, 0.1, 0.5, 10.0
+    total_mass = mass_pole + 1.0
+    x_thr, th_thr = (5, None) if variant == "swingup" else (2.4, 12 * 2 * math.pi / 360)
+
+    def dsdt(s_aug):
+        x, x_dot, theta, theta_dot, force = s_aug
+        pml = mass_pole * length
+        cos_theta, sin_theta = math.cos(theta), math.sin(theta)
+        temp = (force + pml * theta_dot**2 * sin_theta) / total_mass
+        theta_acc = (gravity * sin_theta - cos_theta * temp) / (length * (4.0 / 3.0 - mass_pole * cos_theta**2 / total_mass))
+        x_acc = temp - pml * theta_acc * cos_theta / total_mass
+        return np.array([x_dot, x_acc, theta_dot, theta_acc, 0], dtype=np.float32)
+
+    def batch_reward(obs):
+        return (np.cos(obs[:, 2:3]) + 1) / 2 if variant == "swingup" else np.ones([obs.shape[0], 1])
+
+    def batch_terminal(obs):
+        if variant == "swingup":
+            return ~(np.abs(obs[:, 0:1]) < x_thr)
+        return ~np.logical_and(np.abs(obs[:, 2:3]) < th_thr, np.abs(obs[:, 0:1]) < x_thr)
+
+    rew, term = np.empty(n_steps), np.empty(n_steps, bool)
+    for t in range(n_steps):
+        action = np.asarray(int(actions[t]))
+        s_aug = np.append(state, force_mag if action == 1 else -force_mag)
+        y = s_aug.copy()
+        for _ in range(freq_rate):
+            y += dsdt(y) * dt
+        state = y[:4]
+        obs = state.copy()
+        rew[t] = batch_reward(obs[None])[0, 0]
+        term[t] = batch_terminal(obs[None])[0, 0]
+    return state, rew, term
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle library's parallel loops from now on (libgomp reads OMP_NUM_THREADS only when it loads)."""
+    lib()
+    C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(int(n)))
+
+
 # --------------------------------------------------------------------------- CartPole (NumPy)
 def cartpole_step_numpy(variant, state, action, freq_rate=1, dt=0.02):
     """Vectorised NumPy restatement of base_control.py:61-83 + cartpole.py:48-60: float64 state,

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=16)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--exchange", default="collective")
+    ap.add_argument("--slow-consumer", action="store_true",
+                    help="a consumer on a third stream reads EVERY receive buffer, slowly (zoo/util.py:54-59 reads every obs): "
+                         "under ObsExchange.reading() no buffer may be overwritten before it has been read")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -50,8 +53,22 @@ def main():
         e.set_state(synthetic_init_state(env, world * n, r * n, (r + 1) * n, 0))
         refs.append((e, synthetic_actions(env, T, n, r, world, e.device, 0)))
     K = sr.chunk
+    consumer_stream = torch.cuda.Stream(device=dev)
+    seen = []  # (pass, chunk, copy of the receive buffer as the slow consumer saw it)
+    spin = torch.ones((1024, 1024), device=f"cuda:{dev}")
+
+    def slow_consumer(p):
+        def on_gathered(c, buf):
+            with torch.cuda.stream(consumer_stream):
+                with sr.xchg.reading(buf):
+                    x = spin
+                    for _ in range(40):  # ~ms of work in front of the read: the producer is several collectives ahead by then
+                        x = (x @ spin) * 1e-3
+                    seen.append((p, c, buf.clone(), float(x[0, 0].item() * 0)))
+        return on_gathered
+
     for p in range(a.passes):
-        last = sr.run_pass()
+        last = sr.run_pass(on_gathered=slow_consumer(p) if a.slow_consumer else None)
         sr.wait_gathers()
         torch.cuda.synchronize()
         want = [e.rollout(acts, auto_reset=True)[0] for e, acts in refs]  # [T, n, 4] per rank
@@ -67,6 +84,14 @@ def main():
             for r in range(world):
                 blk = want[r][-1:] if a.gather == "final" else want[r][c * K:(c + 1) * K]
                 assert torch.equal(buf[r], blk), f"pass {p}: collective {c}, block of rank {r}"
+        if a.slow_consumer:  # every buffer the consumer copied out holds the block of ITS collective, of every rank
+            consumer_stream.synchronize()
+            for pp, c, copy, _ in [s for s in seen if s[0] == p]:
+                for r in range(world):
+                    blk = want[r][-1:] if a.gather == "final" else want[r][c * K:(c + 1) * K]
+                    assert torch.equal(copy[r], blk), f"slow consumer, pass {pp}: collective {c}, block of rank {r} was overwritten"
+    if a.slow_consumer:
+        assert len(seen) == a.passes * (1 if a.gather == "final" else sr.n_chunks)
     assert sr.collectives == a.passes * (1 if a.gather == "final" else sr.n_chunks)
     dist.barrier()
     if rank == 0:

@@ -79,6 +79,48 @@ def test_lanes_with_three_row_blocks_vs_oracle(integrator):
     assert eng.solver_cap_hits() == 0
 
 
+def test_three_block_lane_alone_and_among_three_block_wave_mates():
+    """ADVICE r04 / DESIGN "Determinism": a three-block cheetah lane borrows a constraint slot from a wave-mate with at most one
+    row block and otherwise runs the primal loop — the ONE place where a lane's bits depend on who shares its wave.  Pinned here:
+    the same env stepped as an n = 1 engine (63 parked padding lanes = 63 lenders: the constraint-space solver) and inside a wave
+    made of three-block lanes only (no lender: the primal loop) agrees to 1e-11 per step (the two solvers converge to the same
+    minimiser; measured 2e-13), and bit for bit wherever the lane finds a lender (the same env in a wave of free-flight lanes).
+    Sharded-versus-unsharded bit equality therefore needs shard sizes that are multiples of 64 (same wave composition), which is
+    what sharding.py's contiguous blocks of BASELINE's sizes are."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(77)
+    pool = _states(rng, 40000)
+    pool[:, 1] = rng.uniform(-0.45, 0.1, len(pool))
+    nb = np.array([bin(int(m)).count("1") for m in O.planar_row_mask("cheetah", pool)])
+    tri = pool[np.nonzero(nb == 3)[0][:64]]
+    assert len(tri) == 64
+    air = _states(rng, 63)
+    air[:, 1], air[:, 3:9] = 1.0, rng.uniform(-0.2, 0.2, (63, 6))  # high above the floor, joints inside their ranges: no row
+    assert not O.planar_row_mask("cheetah", air).any()
+    act = rng.uniform(-1.0, 1.0, (64, 6)).astype(np.float32)
+    kw = dict(freq_rate=1, real_time_scale=0.002)
+    dense = _engine("HalfCheetahRunning", 64, **kw)  # a wave of three-block lanes: nobody lends
+    dense.set_state(tri)
+    dense.step(torch.as_tensor(act, device=dense.device))
+    got_dense = dense.get_state().cpu().numpy()
+    worst = 0.0
+    for k in (0, 17, 63):
+        alone = _engine("HalfCheetahRunning", 1, **kw)  # the padding lanes of its wave are parked in the air: lenders
+        alone.set_state(tri[k : k + 1])
+        alone.step(torch.as_tensor(act[k : k + 1], device=alone.device))
+        got_alone = alone.get_state().cpu().numpy()[0]
+        worst = max(worst, rel_err(got_dense[k], got_alone, floor=1.0))
+        mixed = _engine("HalfCheetahRunning", 64, **kw)  # the same env at the same lane among free-flight lanes: lenders again
+        st = np.concatenate([air[:k], tri[k : k + 1], air[k:]])
+        a2 = np.concatenate([act[:k], act[k : k + 1], act[k + 1 :]])
+        mixed.set_state(st)
+        mixed.step(torch.as_tensor(a2, device=mixed.device))
+        assert np.array_equal(mixed.get_state().cpu().numpy()[k], got_alone)  # same solver: the same bits
+    assert worst <= 1e-11, worst
+    assert dense.solver_cap_hits() == 0
+
+
 def test_rollout_segments_vs_oracle_and_step_equivalence():
     from oracle import oracle as O
 

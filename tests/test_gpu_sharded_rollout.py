@@ -42,3 +42,15 @@ def test_direct_exchange(gather):
     assert "world=2" in out
     out = _run(1, 29614, "--backend", "nccl", "--gather", gather, "--chunk", "16", "--envs", "65536", "--exchange", "direct")
     assert "world=1 backend=nccl" in out
+
+
+@pytest.mark.parametrize("backend,nproc", [("gloo", 2), ("nccl", 1)])
+def test_slow_consumer_never_sees_an_overwritten_buffer(backend, nproc):
+    """a learner that reads every observation block on a stream of its own (zoo/util.py:54-59 reads every obs)
+    while the producer runs collectives ahead.  The receive buffers alternate, so without the released[b] event the gather two
+    collectives later would overwrite what the consumer is still about to read; under ObsExchange.reading() every copy the
+    consumer takes is the block of its own collective.  2 gloo ranks sharing the GPU, and the 1-rank RCCL group (the asynchronous
+    collective path the 8-GPU run uses)."""
+    out = _run(nproc, 29615 + nproc, "--backend", backend, "--gather", "per_chunk", "--chunk", "8", "--horizon", "64", "--slow-consumer",
+               *(("--envs", "65536") if backend == "nccl" else ()))
+    assert f"world={nproc}" in out

@@ -17,6 +17,7 @@ from emei_amd.sharding import ShardedRollout  # noqa: E402
 
 CASES = (("CartPoleSwingUp", 65536, 1000, 1, 0.02, "euler", "pend_tu_cp0_f64"), ("CartPoleBalancing", 65536, 500, 1, 0.02, "euler", "pend_tu_cp1_f64"),
          ("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, 0.02, "euler", "pend_tu_ip3_f64"),
+         ("BoundaryInvertedPendulumBalancing", 262144, 250, 4, 0.02, "euler", "pend_tu_ip1_f64"),
          ("BoundaryInvertedDoublePendulumSwingUp", 262144, 100, 4, 0.02, "euler", "body_tu_dp3_f64"),
          ("HalfCheetahRunning", 131072, 100, 4, 0.002, "euler", "body_tu_ch_f64"), ("HopperRunning", 131072, 100, 4, 0.002, "rk4", "body_tu_hp_f64"))
 for env, n, T, fr, dt, integ, tu in CASES:

@@ -11,7 +11,8 @@ sys.path.insert(0, ".")
 from emei_amd import _lib  # noqa: E402
 from emei_amd.sharding import ShardedRollout  # noqa: E402
 
-for env, n, T, fr, tu in (("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, "pend_tu_ip3_f64"), ("CartPoleBalancing", 65536, 500, 1, "pend_tu_cp1_f64"),
+for env, n, T, fr, tu in (("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, "pend_tu_ip3_f64"), ("BoundaryInvertedPendulumBalancing", 262144, 250, 4, "pend_tu_ip1_f64"),
+                          ("CartPoleBalancing", 65536, 500, 1, "pend_tu_cp1_f64"),
                           ("CartPoleSwingUp", 65536, 1000, 1, "pend_tu_cp0_f64")):
     sr = ShardedRollout(env, n, T, freq_rate=fr, real_time_scale=0.02)
     sr.make_synthetic_inputs()

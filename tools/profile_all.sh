@@ -4,13 +4,14 @@
 # Usage: tools/profile_all.sh <round> [workload ...]
 set -e
 RND=${1:-r02}; shift || true
-WL=${@:-cartpole_swingup cartpole_balancing invpend dpend cheetah cheetah_sweep1 hopper hopper_sweep1}
+WL=${@:-cartpole_swingup cartpole_balancing invpend invpend_balancing dpend cheetah cheetah_sweep1 hopper hopper_sweep1}
 mkdir -p gpurun_out/profiles_$RND
 for w in $WL; do
   case $w in
     cartpole_swingup)   ARGS="--workload cartpole_swingup";   PAT=pend_rollout_staged; N=65536;  T=1000; B=22;  ;;
     cartpole_balancing) ARGS="--workload cartpole_balancing"; PAT=pend_rollout_staged; N=65536;  T=500;  B=22;  ;;
     invpend)            ARGS="--workload invpend";            PAT=pend_rollout_staged; N=262144; T=250;  B=25;  ;;
+    invpend_balancing)  ARGS="--workload invpend_balancing";  PAT=pend_rollout_staged; N=262144; T=250;  B=25;  ;;
     dpend)              ARGS="--workload dpend";              PAT=body_rollout;        N=262144; T=100;  B=33;  ;;
     cheetah)            ARGS="--workload cheetah";            PAT=body_rollout;        N=131072; T=100;  B=101; ;;
     cheetah_sweep1)     ARGS="--workload cheetah --solver sweep1"; PAT=body_rollout;   N=131072; T=100;  B=101; ;;
