@@ -352,6 +352,44 @@ __device__ __forceinline__ void ip_limit_rows(const IpModel& m, R x, R th, R v0,
     a1 = fma_r(fma_r((R)m.M11, g1, -(M12 * g0)), idet, a1);
 }
 
+// The same solve for a lane that is beyond BOTH stops (the only lanes the staged kernel's cold path keeps a result for:
+// InvPend::substep), bit for bit — J = +-1 is a sign, recomputed where it is used instead of kept; no "is this row on" selects;
+// the two-row solution first, the single-row ones after it.  Written for its register footprint: with ip_limit_rows the
+// Balancing variants needed one float64 more than the 128 registers of a 4-waves-per-SIMD kernel (12 B of scratch; round 5).
+template <typename R>
+__device__ __forceinline__ void ip_limit_both(const IpModel& m, R x, R th, R v0, R v1, R M12, R idet, R limK, R limB, R& a0, R& a1) {
+    auto row = [&](R qi, R vi, R lo, R hi, R invw, R Mdd, R ai, R& bi, R& Hii) __attribute__((always_inline)) {
+        const bool low = qi < lo;
+        const R dist = low ? qi - lo : hi - qi;
+        const R xx = fabs(dist) * (R)m.inv_width;
+        const R u1 = R(1) - xx;
+        const R y = xx >= R(1) ? R(1) : (xx <= R(0.5) ? R(2) * xx * xx : fma_r(R(-2) * u1, u1, R(1)));
+        const R imp = fma_r(y, (R)(m.dmax - m.dmin), (R)m.dmin);
+        const R Jv = low ? vi : -vi, Ja = low ? ai : -ai;
+        bi = fma_r(-limK * imp, dist, -limB * Jv) - Ja;
+        Hii = fma_r(Mdd, idet, div_r(R(1) - imp, imp) * invw);
+    };
+    R b0, b1, H00, H11;
+    row(x, v0, (R)m.x_lo, (R)m.x_hi, (R)m.invw, (R)m.M22, a0, b0, H00);
+    row(th, v1, (R)m.th_lo, (R)m.th_hi, (R)m.invw_hinge, (R)m.M11, a1, b1, H11);
+    const R mA = M12 * idet;
+    const R A01 = ((x < (R)m.x_lo) == (th < (R)m.th_lo)) ? -mA : mA;  // J0 J1 (-M12 idet)
+    const R id2 = rcp_r(fma_r(H00, H11, -(A01 * A01)));
+    const R t0 = fma_r(H11, b0, -(A01 * b1)) * id2, t1 = fma_r(H00, b1, -(A01 * b0)) * id2;  // both rows
+    const bool both = (t0 > R(0)) & (t1 > R(0));
+    const R s0 = div_r(b0, H00);  // one row alone
+    const bool only0 = !both & (s0 > R(0)) & !(b1 - A01 * s0 > R(0));
+    const R s1 = div_r(b1, H11);
+    const bool only1 = !both & !only0 & (s1 > R(0)) & !(b0 - A01 * s1 > R(0));
+    const R f0 = both ? t0 : (only0 ? s0 : R(0)), f1 = both ? t1 : (only1 ? s1 : R(0));
+    const R g0 = x < (R)m.x_lo ? f0 : -f0, g1 = th < (R)m.th_lo ? f1 : -f1;  // J' f
+    a0 = fma_r(fma_r((R)m.M22, g0, -(M12 * g1)), idet, a0);
+    a1 = fma_r(fma_r((R)m.M11, g1, -(M12 * g0)), idet, a1);
+}
+
+#ifndef EMEI_IP_BAL_WAVES
+#define EMEI_IP_BAL_WAVES 4  // waves per SIMD the Balancing variants are compiled for (see kMinWavesPerEU; 3 = rounds 3-4, for A/B runs)
+#endif
 template <int VARIANT, typename R>
 struct InvPend {
     using real = R;
@@ -365,11 +403,11 @@ struct InvPend {
     // config 3: some lane of a wave resets in 95 % of its env-steps (random pushes of +-300 N run the cart off the rail in
     // ~20 steps): the reset block is laid out in line, not behind two taken branches
     static constexpr bool kResetLikely = true;
-    // The SwingUp variants (BASELINE configs[2] is BoundarySwingUp) are compiled for 4 waves per SIMD (<= 128 registers).  The
-    // Balancing variants carry the two-row limit solve of the hinge stop (ip_limit_rows, a cold path): under the 128-register
-    // cap it spilled 12-20 B to scratch (scratch traffic shares vmcnt with the staged tile loads: tests/test_isa_guards.py),
-    // so they are compiled for 3 waves per SIMD — at 262 144 envs their fourth wave queues instead of being resident.
-    static constexpr int kMinWavesPerEU = VARIANT >= 2 ? 4 : 3;
+    // Every variant is compiled for 4 waves per SIMD (<= 128 registers, no scratch: tests/test_isa_guards.py).  Rounds 3-4 ran the
+    // Balancing variants at 3: their two-row limit solve of the hinge stop (a cold path) needed one float64 more than 128 registers
+    // hold; round 5 rewrote it for the lanes that are beyond both stops (ip_limit_both): 0.744 -> 0.696 ms per launch at
+    // 262 144 envs (the fourth wave of a SIMD used to queue behind the first three).
+    static constexpr int kMinWavesPerEU = VARIANT >= 2 ? 4 : EMEI_IP_BAL_WAVES;
     __device__ static constexpr const IpModel& km() { return VARIANT >= 2 ? kIpHanging : kIpUpright; }
     // The dynamics only use mpr * sin(phi) and mpr * cos(phi), phi = theta + phi_off: the float64 kernels stage the {sin,cos}
     // table rotated by phi_off and pre-multiplied by the pole's mass moment (emei_device.h:stage_trig_table), look theta
@@ -505,7 +543,7 @@ struct InvPend {
         }
         if (__builtin_expect(VARIANT < 2 && __ballot(hinge) != 0ull, 0)) {
             if (__builtin_expect(__ballot(hinge & beyond) != 0ull, 0)) {
-                if (hinge & beyond) ip_limit_rows(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
+                if (hinge & beyond) ip_limit_both(m, x_old, th_old, v_old, om_old, Q, idet, (R)p.limK, (R)p.limB, a0, a1);
             }
             if (hinge & !beyond) limit_row(std::integral_constant<int, 1>{});
             else if (beyond & !hinge) limit_row(std::integral_constant<int, 0>{});

@@ -35,6 +35,39 @@ def test_self_launch_refuses_a_profiler_preload():
     assert p.returncode == 2 and "profiler" in p.stderr and not p.stdout.strip()
 
 
+def test_self_launch_accepts_a_profiler_path_variable_without_a_preload():
+    """module files and containers export ROCPROFILER_* / ROCP_* variables (paths, register settings) with no
+    profiler attached — not a reason to refuse; and --allow-profiler-env overrides a detected preload.  Without a GPU the ranks
+    then fail at bench.py's own check, which proves the launcher was started."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_bench_contract.py")
+    for extra_env, extra_args in (({"ROCPROFILER_METRICS_PATH": "/opt/rocm/share/rocprofiler-sdk", "ROCP_HSA_INTERCEPT": "0"}, []),
+                                  ({"ROCPROFILER_REGISTER_FORCE_LOAD": "1"}, ["--allow-profiler-env"])):
+        e = dict(os.environ, **extra_env)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            e.pop(k, None)
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"] + extra_args, cwd=ROOT, env=e,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode not in (0, 2) and "needs a GPU" in p.stderr, (extra_env, p.stderr[-500:])
+
+
+def test_rccl_summary_parses_an_info_log(tmp_path):
+    """bench.rccl_summary: best-effort reading of NCCL_DEBUG=INFO output (version, ranks, the lines naming algorithm / protocol)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    log = tmp_path / "rccl.log"
+    log.write_text("host:1:1 [0] NCCL INFO RCCL version 2.22.3+hip6.4\n"
+                   "host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START\n"
+                   "host:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\nhost:1:1 [0] NCCL INFO Channel 15/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                   "host:1:1 [0] NCCL INFO AllGather: opCount 0 sendbuff 0x1 recvbuff 0x2 count 16777216 datatype 7 -> algo 1 proto 2 time 1.5\n")
+    r = bench.rccl_summary(str(log), 8)
+    assert r["version"].startswith("2.22") and r["nranks"] == 8 and r["expected_nranks"] == 8 and r["channels"] == 16
+    assert len(r["algo_proto_lines"]) == 1 and "algo 1 proto 2" in r["algo_proto_lines"][0]
+    assert "error" in bench.rccl_summary(str(tmp_path / "missing.log"), 8)
+
+
 def test_parent_never_imports_torch_before_launching():
     """the self-launching parent must not initialise the GPU (a later exec / fork from such a process takes the box down):
     its code path ends in self_launch() before the first `import torch`"""

@@ -61,6 +61,14 @@ def test_default_single_gpu_line():
     assert j["ms_per_step"] >= j["roofline"]["kernel_ms"] * 0.98
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # SURVEY 8d's other two CPU numbers: the same C rollout on one thread, and the reference's own call pattern
+    one, ref = c["one_core"], c["reference_style"]
+    assert one["cores"] == 1 and 0 < one["value"] <= c["value"] * 1.05 and one["sample"]
+    assert ref["cores"] == 1 and 1e3 < ref["value"] < one["value"] and ref["ms_per_1000_steps"] == pytest.approx(1e6 / ref["value"], rel=1e-6)
+    r = j["roofline"]
+    assert isinstance(r["profile_stale"], bool)
+    if r["profile_kernel_avg_us"]:
+        assert r["profile_stale"] == (abs(r["kernel_ms"] * 1e3 - r["profile_kernel_avg_us"]) > 0.1 * r["profile_kernel_avg_us"])
     assert j["value"] > 1e7  # north_star's floor
 
 
@@ -102,6 +110,24 @@ def test_two_rank_line_over_gloo_sharing_the_gpu(how):
     vf = j["value_final_gather"]
     assert vf["gather"] == "final" and vf["value"] == pytest.approx(2 * 131072 * 1000 / (vf["ms_per_step"] * 1e-3), rel=1e-6)
     assert vf["value"] >= 0.9 * j["value"]
+    # the other form of the exchange (batched point-to-point transfers) timed in the same run, same gather mode
+    vd = j["value_direct_exchange"]
+    assert vd["exchange"] == "direct" and vd["gather"] == "per_chunk" and vd["unit"] == "env-steps/s"
+    assert vd["value"] == pytest.approx(2 * 131072 * 1000 / (vd["ms_per_step"] * 1e-3), rel=1e-6) and vd["xgmi_inbound_gbs"] > 0
+    assert "rccl" not in j  # gloo rehearsal: RCCL's own report is switched on for the nccl backend only
+
+
+def test_collective_is_the_other_exchange_when_direct_is_the_runs_own():
+    steps, warmup = 2, 1
+    e = dict(os.environ, EMEI_BENCH_SHARE_GPU="1", EMEI_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--exchange", "direct",
+                        "--envs-per-gpu", "16384"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["exchange"] == "direct" and j["value_collective_exchange"]["exchange"] == "collective"
+    assert "value_direct_exchange" not in j
 
 
 def test_a_failing_rank_fails_the_self_launched_bench():
@@ -120,4 +146,5 @@ def test_other_workloads_carry_their_own_cpu_baseline():
         j = _line([sys.executable, "bench.py", "--workload", wl, "--steps", "3", "--warmup", "1"], timeout=600)
         c = j["cpu_baseline"]
         assert c["kind"] == "port" and c["value"] > 0 and frac in c["sample"] and c["cores"] >= 1
+        assert c["one_core"]["cores"] == 1 and 0 < c["one_core"]["value"] <= c["value"] * 1.05
         assert j["launch"]["ranks"] == 1

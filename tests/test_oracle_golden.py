@@ -71,6 +71,19 @@ def test_cartpole_rk4_differs_from_euler(cartpole_golden, cartpole_rk4_golden):
     assert np.abs(st_e[100, 0] - g["traj_swingup_fr1_seed0_states"][100]).max() > 1e-4
 
 
+@pytest.mark.parametrize("name", ["swingup", "balancing"])
+def test_reference_style_loop_equals_the_c_oracle(name):
+    """bench.py's `cpu_baseline.reference_style` (oracle.cartpole_reference_style_loop: one env, a CPython call per step, scalar
+    math.sin / cos, float32 np.array derivative — the call pattern of base_control.py:61-83 and of BASELINE configs[0]) computes
+    what the pinned C oracle computes, bit for bit, over 1000 steps."""
+    st, rew, term = O.cartpole_reference_style_loop(name, 1000, 0)
+    s0 = O.cartpole_init_state_host(name, 0, 1)
+    acts = np.random.default_rng(1).integers(2, size=1000)
+    S, R, T = O.cartpole_rollout(name, s0, acts[:, None])
+    assert np.array_equal(S[-1, 0], st) and np.array_equal(T[:, 0], term)
+    assert rel_err(rew, R[:, 0], floor=1e-300) <= 4e-16
+
+
 def test_baseline_md_first_rows(cartpole_golden):
     """The values quoted in BASELINE.md / SURVEY.md 8c: reset(seed=0) then actions 0, 1, 1."""
     s0 = O.cartpole_init_state_host("swingup", 0, 1)
