@@ -194,7 +194,11 @@ EMEI_API int emei_abi_version(void);
  *       root: world)}; per capsule in XML order {body, end-sphere centre 0 x, z, centre 1 x, z (body frame), radius, pair friction
  *       with the floor}; per actuated joint {stiffness, damping, armature, range lo, hi (rad), gear}; contact margin, contact
  *       solref time constant, solimp dmin, dmax, width, limit solref time constant, solimp dmin, dmax, width, ctrlrange lo, hi,
- *       rootz ref, sign of the leg hinges' axis (+1: +y, -1: -y) */
+ *       rootz ref, sign of the leg hinges' axis (+1: +y, -1: -y)
+ *
+ * WHICH FILE: these are the constants of emei's OWN XML files under emei/envs/mujoco/assets.  An installed reference passes a RELATIVE
+ * model_path (inverted_pendulum.py:28, half_cheetah.py:48) to gym's MujocoEnv, which resolves it against GYM's assets directory —
+ * gym's files are not in the build image, the fields in which they differ from emei's are unknown. */
 EMEI_API int emei_model_constants(int env_id, double* out, int capacity);
 
 /* Debug / test getter: the qpos0 inverse weights (MuJoCo's mj_setConst: dof_invweight0 = (M0^-1)_jj of a joint, body_invweight0 =
