@@ -28,6 +28,9 @@ constexpr int kWave = 64;
 static __device__ unsigned long long g_debug_stats[32];
 #endif
 #ifdef EMEI_CLOCK_PROBE
+#ifndef EMEI_CLOCK_BIN_TICKS
+#define EMEI_CLOCK_BIN_TICKS 5000  // 50 us
+#endif
 struct ClockProbe {
     unsigned long long c0, r0;
     __device__ __forceinline__ void begin() { c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -40,6 +43,14 @@ struct ClockProbe {
             // of two readings of ONE counter; slot 26: ticks spent waiting for a predecessor work item (body_kernels.h:WorkQueue)
             atomicMax(&g_debug_stats[27], r1), atomicMax(&g_debug_stats[31], ~r0);
             atomicMax(&g_debug_stats[23], r1 - r0);  // the longest single lifetime
+#ifndef EMEI_NEWTON_STATS
+            // histogram of lifetimes in EMEI_CLOCK_BIN_TICKS bins (slots 0-15; tools/pend_span.py): are the waves of a SIMD served fairly?
+#ifdef EMEI_CLOCK_HIST_WAVEID  // ... or of the waves' slot ids on their SIMD (HW_REG_HW_ID bits [3:0])
+            atomicAdd(&g_debug_stats[__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 15u], 1ull);
+#else
+            atomicAdd(&g_debug_stats[(r1 - r0) / EMEI_CLOCK_BIN_TICKS < 15 ? (r1 - r0) / EMEI_CLOCK_BIN_TICKS : 15], 1ull);
+#endif
+#endif
         }
     }
     // a persistent worker leaves (no ticket left): slot 21 workers, slot 22 the sum of their exit ticks — the mean exit against the

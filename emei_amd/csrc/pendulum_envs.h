@@ -55,6 +55,7 @@ struct CartPole {
     // of the reset path lives in them
     static constexpr bool kSpareInLds = false;
     static constexpr bool kSpareFlagInVgpr = false;
+    static constexpr bool kRotatePriority = false;  // pendulum_kernels.h: rotate_priority
     // Balancing under random actions: the pole falls within ~20 steps, some lane of a wave resets in 95 % of its env-steps
     // (SwingUp: 20 %) — the reset block in line (pendulum_kernels.h:maybe_reset)
     static constexpr bool kResetLikely = VARIANT == 1;
@@ -400,6 +401,7 @@ struct InvPend {
     // of LDS per block): the spare initial state of the reset path goes to LDS, the rollout is compiled for 4 waves
     static constexpr bool kSpareInLds = true;
     static constexpr bool kSpareFlagInVgpr = true;  // pendulum_kernels.h:maybe_reset
+    static constexpr bool kRotatePriority = true;   // four waves per SIMD, bound by vector issue: pendulum_kernels.h:rotate_priority
     // config 3: some lane of a wave resets in 95 % of its env-steps (random pushes of +-300 N run the cart off the rail in
     // ~20 steps): the reset block is laid out in line, not behind two taken branches
     static constexpr bool kResetLikely = true;

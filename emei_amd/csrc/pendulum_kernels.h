@@ -156,6 +156,9 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 // steps per staged tile: 16 for one-byte actions (1 KiB of LDS per wave and buffer); 8 for 4- and 8-byte actions, so that
 // the double-buffered tiles of a 256-thread block stay at 16 / 32 KiB and four blocks (with the other slices) fit a CU's
 // 160 KiB: config 3 runs 4 waves per SIMD
+#ifndef EMEI_PRIO_ROTATE
+#define EMEI_PRIO_ROTATE 1  // 0: a variant build without the priority rotation of the staged kernel, for A/B runs
+#endif
 template <typename ActT>
 constexpr int stage_steps() { return sizeof(ActT) == 1 ? 16 : 8; }
 
@@ -302,6 +305,24 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
         if (kStage == 16 || lane < 4 * kStage) *(uint4*)(a.done_out + row0 * n + done_lane_off) = v;  // kStage rows x 64 B
     };
 
+    // Issue priority (Env::kRotatePriority: the InvertedPendulum kernels).  The SIMD's arbiter serves the OLDEST of its ready waves
+    // first: of the four waves that share a SIMD (config 3) the first finishes after 45 % of the launch, the second after 60 %,
+    // the third after 80 % (lifetimes in four clean groups of 1024 waves, profiles/r05_clock_probe.txt) and the SIMD ends the
+    // launch with one wave.  Every tile the wave sets its priority to (tile + its wave slot) mod 4 — slots are 0..3, measured —
+    // so that each of the four is the favoured one a quarter of the time.  Worth 6 % for the Balancing variants (0.683 -> 0.643 ms),
+    // 0-3 % for SwingUp; finer rotation (every step, every two) is no better; for the HBM-bound CartPole kernel at two waves per
+    // SIMD it was -8 % on one box and +4 % on another: not applied there.  s_setprio takes an immediate, hence the switch.
+    const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;  // HW_REG_HW_ID (4), WAVE_ID = bits [3:0]
+    auto rotate_priority = [&](uint32_t tile) __attribute__((always_inline)) {
+#if EMEI_PRIO_ROTATE
+        if constexpr (Env::kRotatePriority) switch ((tile + wave_slot) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
+    };
     EMEI_LOAD_TILE(0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t0 = 0, buf = 0;
@@ -314,6 +335,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     uint4 done_pend = make_uint4(0u, 0u, 0u, 0u);
     for (; t0 + kStage <= a.n_steps; t0 += kStage, buf ^= 1) {
         EMEI_LOAD_TILE(t0 + kStage, buf ^ 1)  // next tile: in flight under the 16 steps below
+        rotate_priority((uint32_t)(t0 / kStage));
         const ActT* act_l = (const ActT*)&act_s[wv][buf][0];
         ActT act_cur = act_l[lane];
         // 16 steps = 4 groups x 4 unrolled steps (one reward flush period), the group loop unrolled by two: at the loop's

@@ -21,3 +21,4 @@ for env, n, T, fr, tu in (("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, "p
     span = (end - ((~nbegin) & M64)) / 20.0  # 20 back-to-back launches: first begin to last end
     items //= 20; ticks /= 20; cyc /= 20
     print(f"{env} n={n}: kernel {ms*1e3:.1f} us, waves {items}, mean lifetime {ticks/items/100:.1f} us, longest {longest/100:.1f} us, span {span/100:.1f} us, mean/span {ticks/items/span*100:.1f} %, clock {cyc/ticks*0.1:.3f} GHz", flush=True)
+    print("    lifetimes in 50 us bins (waves per launch):", " ".join(str(int(out[k]) // 20) for k in range(16)), flush=True)
