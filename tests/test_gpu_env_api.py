@@ -209,3 +209,19 @@ def test_step_host_equals_step_plus_get_obs(name, n):
         assert np.array_equal(o32, obs.cpu().numpy()) and np.array_equal(rew, r.cpu().numpy()) and np.array_equal(done, d.cpu().numpy())
         assert np.array_equal(o64, b_eng.get_obs().cpu().numpy())
     assert (np.asarray(done) >= 0).all()
+
+
+def test_step_host_after_close_raises_instead_of_faulting():
+    """`Engine.step_host` pre-binds the raw handle into a ctypes call; after `close()` that call held a dangling
+    `emei_env*`.  close() drops it, a later step_host raises."""
+    from emei_amd import _lib
+    from emei_amd.engine import Engine
+
+    eng = Engine("CartPoleSwingUp", 1)
+    eng.reset(0)
+    eng.step_host(1)
+    eng.close()
+    assert eng._host_io is None and eng._host_bufs is None
+    with pytest.raises(_lib.EmeiHipError, match="closed"):
+        eng.step_host(1)
+    eng.close()  # idempotent
