@@ -182,7 +182,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     __shared__ SinCosEntry trig_s[kTrigTableSize];
     stage_trig_table(trig_s, a.trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#ifdef EMEI_BLOCK_SWIZZLE  // experiment: which env block a workgroup (and so an XCD: workgroups go to XCDs round-robin) works on
+    const int64_t i = (int64_t)(blockIdx.x ^ (unsigned)EMEI_BLOCK_SWIZZLE) * kBlock + threadIdx.x;
+#else
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
+#endif
     if (i >= a.n) return;
     EMEI_CLOCK_BEGIN();
     const int64_t n = a.n;

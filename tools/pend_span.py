@@ -21,4 +21,8 @@ for env, n, T, fr, tu in (("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, "p
     span = (end - ((~nbegin) & M64)) / 20.0  # 20 back-to-back launches: first begin to last end
     items //= 20; ticks /= 20; cyc /= 20
     print(f"{env} n={n}: kernel {ms*1e3:.1f} us, waves {items}, mean lifetime {ticks/items/100:.1f} us, longest {longest/100:.1f} us, span {span/100:.1f} us, mean/span {ticks/items/span*100:.1f} %, clock {cyc/ticks*0.1:.3f} GHz", flush=True)
-    print("    lifetimes in 50 us bins (waves per launch):", " ".join(str(int(out[k]) // 20) for k in range(16)), flush=True)
+    if "--xcc" in sys.argv:  # a -DEMEI_CLOCK_HIST_XCC build: mean lifetime per XCD
+        print("    mean lifetime per XCD (us):", " ".join(f"{int(out[k]) / max(int(out[8 + k]), 1) / 100:.1f}" for k in range(8)),
+              " waves per XCD:", " ".join(str(int(out[8 + k]) // 20) for k in range(8)), flush=True)
+    else:
+        print("    lifetimes in 50 us bins (waves per launch):", " ".join(str(int(out[k]) // 20) for k in range(16)), flush=True)
