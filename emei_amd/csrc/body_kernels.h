@@ -676,10 +676,10 @@ static int launch_body(const BodyLaunch& L) {
             a.cap_hits = L.cap_hits;
             a.work = nullptr, a.chunk_steps = 0, a.n_waves = rgrid.x, a.n_items = 0;
             if constexpr (rollout_block<Body>() == kWave && EMEI_WORKQUEUE != 0) {
-                // chunked launch (WorkQueue).  Automatic policy (0): only when the shard has more waves than the device holds at
-                // once (otherwise every wave is resident from the start and there is nothing to balance), the guided schedule
-                // with a quarter of the remaining steps per item.  emei_config encodes: k > 0 fixed length, -1 off, and — for
-                // experiments — -(100 + g): the guided schedule with 1 / 2^g
+                // chunked launch (WorkQueue).  emei_config.rollout_chunk_steps: k > 0 fixed length; -1 off; -(100 m + g) the guided
+                // schedule with 1 / 2^g of the remaining steps per chunk, at least m; 0 automatic: only when the shard has more
+                // waves than the device holds at once (otherwise every wave is resident from the start and there is nothing to
+                // balance), guided with kGuidedShift / kGuidedMin
                 int cs = L.chunk_steps;
                 // (device encoding of a guided schedule: -((shortest item << 4) | g))
                 if (cs == 0) cs = (L.resident_waves > 0 && (int64_t)rgrid.x > L.resident_waves) ? -((kGuidedMin << 4) | kGuidedShift) : 0;
