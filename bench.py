@@ -323,7 +323,7 @@ def main():
         if backend == "nccl" and not a.no_rccl_info and "NCCL_DEBUG" not in os.environ:
             # what RCCL chose (ranks, channels, algorithm / protocol of the all-gather) goes into the line: its INFO log, per rank, to a file
             rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"emei_bench_rccl_{os.getpid()}_r{rank}.log")
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,ENV,TUNING,COLL", NCCL_DEBUG_FILE=rccl_log)
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,ENV,TUNING", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
