@@ -34,6 +34,9 @@ struct PendParams {
 // CartPole — emei/envs/classic_control/cartpole.py
 // VARIANT 0 = SwingUp (:135-156), 1 = Balancing (:115-132)
 // =============================================================================================
+#ifndef EMEI_SPLIT_MAX_ROUNDS
+#define EMEI_SPLIT_MAX_ROUNDS 3
+#endif
 template <int VARIANT, typename R>
 struct CartPole {
     using real = R;
@@ -56,6 +59,10 @@ struct CartPole {
     static constexpr bool kSpareInLds = false;
     static constexpr bool kSpareFlagInVgpr = false;
     static constexpr bool kRotatePriority = false;  // pendulum_kernels.h: rotate_priority
+    // pendulum_kernels.h:launch_rollout_full — bound by its write stream: shards of 2 .. kSplitMaxRounds waves per SIMD run as consecutive
+    // launches of one wave per SIMD (set from the sweep in profiles/r05_split_launch.txt)
+    static constexpr bool kSplitLaunch = true;
+    static constexpr unsigned kSplitMaxRounds = EMEI_SPLIT_MAX_ROUNDS;
     // Balancing under random actions: the pole falls within ~20 steps, some lane of a wave resets in 95 % of its env-steps
     // (SwingUp: 20 %) — the reset block in line (pendulum_kernels.h:maybe_reset)
     static constexpr bool kResetLikely = VARIANT == 1;
@@ -402,6 +409,8 @@ struct InvPend {
     static constexpr bool kSpareInLds = true;
     static constexpr bool kSpareFlagInVgpr = true;  // pendulum_kernels.h:maybe_reset
     static constexpr bool kRotatePriority = true;   // four waves per SIMD, bound by vector issue: pendulum_kernels.h:rotate_priority
+    static constexpr bool kSplitLaunch = false;     // ... and wants its four resident waves
+    static constexpr unsigned kSplitMaxRounds = 0;
     // config 3: some lane of a wave resets in 95 % of its env-steps (random pushes of +-300 N run the cart off the rail in
     // ~20 steps): the reset block is laid out in line, not behind two taken branches
     static constexpr bool kResetLikely = true;

@@ -33,6 +33,7 @@ struct RolloutArgs {
     double* obs_f64;
     uint32_t* host_flag;
     uint32_t flag_value;
+    uint32_t first_block;  // staged kernel: a launch may cover the blocks [first_block, first_block + gridDim.x) of the shard (launch_rollout_full)
 };
 
 // emei_step (n_steps = 1) and emei_rollout (n_steps = T): base_control.py:61-83 /
@@ -183,9 +184,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     stage_trig_table(trig_s, a.trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
 #ifdef EMEI_BLOCK_SWIZZLE  // experiment: which env block a workgroup (and so an XCD: workgroups go to XCDs round-robin) works on
-    const int64_t i = (int64_t)(blockIdx.x ^ (unsigned)EMEI_BLOCK_SWIZZLE) * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)((blockIdx.x + a.first_block) ^ (unsigned)EMEI_BLOCK_SWIZZLE) * kBlock + threadIdx.x;
 #else
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
+    const int64_t i = (int64_t)(blockIdx.x + a.first_block) * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
 #endif
     if (i >= a.n) return;
     EMEI_CLOCK_BEGIN();
@@ -529,18 +530,44 @@ __global__ void __launch_bounds__(kBlock)
 // ---------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+#ifndef EMEI_SPLIT_LAUNCH
+#define EMEI_SPLIT_LAUNCH 1  // 0: a variant build without the split of large HBM-bound launches, for A/B runs
+#endif
+// CUs of the current device (cached: the launch path neither allocates nor synchronises; an attribute query is neither)
+static inline int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+    return cus[dev];
+}
+
 template <class Env, typename ActT>
 static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
     const bool full = a.obs_out && a.reward_out && a.done_out;
     if (full && a.n_steps >= stage_steps<ActT>() && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
         aligned16(a.reward_out) && aligned16(a.done_out))
     {
-        if (a.freq_rate == 1) {
-            hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
-            return EMEI_KERNEL_PEND_STAGED_FREQ1;
+        // Env::kSplitLaunch (the HBM-bound CartPole kernels): a shard of 2 or 3 waves per SIMD (BASELINE configs[4]'s 131 072 envs per GPU)
+        // runs as consecutive launches of ONE wave per SIMD each (one 256-thread block per CU): co-resident waves' write streams
+        // get in each other's way at that occupancy.  Same box: 131 072 envs 0.706 -> 0.671 ms, 196 608 0.976 -> 0.912; nothing at
+        // 4 waves per SIMD, +8 % (worse) at 8, nothing at 16 — hence kSplitMaxRounds = 3 (profiles/r05_split_launch.txt).  Envs are
+        // independent: the same bits.
+        unsigned per_launch = grid.x;
+        if constexpr (EMEI_SPLIT_LAUNCH != 0 && Env::kSplitLaunch) {
+            const unsigned round = (unsigned)device_cus();  // blocks of one wave per SIMD
+            if (grid.x > round && grid.x <= Env::kSplitMaxRounds * round) per_launch = round;
         }
-        hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), grid, dim3(kBlock), 0, stream, a);
-        return EMEI_KERNEL_PEND_STAGED;
+        RolloutArgs<Env> b = a;
+        for (unsigned first = 0; first < grid.x; first += per_launch) {
+            b.first_block = first;
+            const dim3 g(min(per_launch, grid.x - first));
+            if (a.freq_rate == 1)
+                hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), g, dim3(kBlock), 0, stream, b);
+            else
+                hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), g, dim3(kBlock), 0, stream, b);
+        }
+        return a.freq_rate == 1 ? EMEI_KERNEL_PEND_STAGED_FREQ1 : EMEI_KERNEL_PEND_STAGED;
     }
     if (full) {
         hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
@@ -577,6 +604,7 @@ static int launch_env(const PendLaunch& L) {
     a.obs_f64 = L.op == PEND_OP_ROLLOUT ? L.obs_f64 : nullptr;
     a.host_flag = L.op == PEND_OP_ROLLOUT ? L.host_flag : nullptr;
     a.flag_value = L.flag_value;
+    a.first_block = 0;
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case PEND_OP_ROLLOUT: {
