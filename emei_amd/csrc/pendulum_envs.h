@@ -63,6 +63,7 @@ struct CartPole {
     // launches of one wave per SIMD (set from the sweep in profiles/r05_split_launch.txt)
     static constexpr bool kSplitLaunch = true;
     static constexpr unsigned kSplitMaxRounds = EMEI_SPLIT_MAX_ROUNDS;
+    static constexpr bool kXcdContiguous = true;  // pendulum_kernels.h: the env_block map of large shards
     // Balancing under random actions: the pole falls within ~20 steps, some lane of a wave resets in 95 % of its env-steps
     // (SwingUp: 20 %) — the reset block in line (pendulum_kernels.h:maybe_reset)
     static constexpr bool kResetLikely = VARIANT == 1;
@@ -395,6 +396,9 @@ __device__ __forceinline__ void ip_limit_both(const IpModel& m, R x, R th, R v0,
     a1 = fma_r(fma_r((R)m.M11, g1, -(M12 * g0)), idet, a1);
 }
 
+#ifndef EMEI_IP_XCD_CONTIGUOUS
+#define EMEI_IP_XCD_CONTIGUOUS 0  // the InvertedPendulum kernels are not bound by their write stream: identity map (A/B: nothing)
+#endif
 #ifndef EMEI_IP_BAL_WAVES
 #define EMEI_IP_BAL_WAVES 4  // waves per SIMD the Balancing variants are compiled for (see kMinWavesPerEU; 3 = rounds 3-4, for A/B runs)
 #endif
@@ -411,6 +415,7 @@ struct InvPend {
     static constexpr bool kRotatePriority = true;   // four waves per SIMD, bound by vector issue: pendulum_kernels.h:rotate_priority
     static constexpr bool kSplitLaunch = false;     // ... and wants its four resident waves
     static constexpr unsigned kSplitMaxRounds = 0;
+    static constexpr bool kXcdContiguous = EMEI_IP_XCD_CONTIGUOUS != 0;
     // config 3: some lane of a wave resets in 95 % of its env-steps (random pushes of +-300 N run the cart off the rail in
     // ~20 steps): the reset block is laid out in line, not behind two taken branches
     static constexpr bool kResetLikely = true;

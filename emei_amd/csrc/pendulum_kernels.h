@@ -33,6 +33,7 @@ struct RolloutArgs {
     double* obs_f64;
     uint32_t* host_flag;
     uint32_t flag_value;
+    uint32_t xcd_contiguous;  // staged kernel: see the env_block map (set by launch_rollout_full when gridDim.x % 8 == 0)
     uint32_t first_block;  // staged kernel: a launch may cover the blocks [first_block, first_block + gridDim.x) of the shard (launch_rollout_full)
 };
 
@@ -183,10 +184,16 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     __shared__ SinCosEntry trig_s[kTrigTableSize];
     stage_trig_table(trig_s, a.trig, Env::trig_rot_c(), Env::trig_rot_s());
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#ifdef EMEI_BLOCK_SWIZZLE  // experiment: which env block a workgroup (and so an XCD: workgroups go to XCDs round-robin) works on
+#if defined(EMEI_BLOCK_SWIZZLE)  // experiment: which env block a workgroup (and so an XCD) works on
     const int64_t i = (int64_t)((blockIdx.x + a.first_block) ^ (unsigned)EMEI_BLOCK_SWIZZLE) * kBlock + threadIdx.x;
 #else
-    const int64_t i = (int64_t)(blockIdx.x + a.first_block) * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
+    // Which env block a workgroup works on.  Workgroups go to the 8 XCDs round-robin (workgroup b -> XCD b mod 8).  With
+    // a.xcd_contiguous (shards of more than one wave per SIMD: launch_rollout_full) XCD k gets ONE contiguous eighth of the launch's
+    // envs, i.e. of every output row, instead of every eighth 4 KiB piece: 131 072 envs 0.676 -> 0.615 ms, 1 048 576 envs 5.61 ->
+    // 5.01 ms on one box; nothing (or slightly worse) at 65 536 envs, where the identity stays (profiles/r05_split_launch.txt).
+    // Results do not depend on it (envs are independent); the map is fixed, so an env's lines stay in one XCD's L2 across launches.
+    const unsigned env_block = a.xcd_contiguous ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t i = (int64_t)(env_block + a.first_block) * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
 #endif
     if (i >= a.n) return;
     EMEI_CLOCK_BEGIN();
@@ -530,6 +537,9 @@ __global__ void __launch_bounds__(kBlock)
 // ---------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+#ifndef EMEI_XCD_CONTIGUOUS
+#define EMEI_XCD_CONTIGUOUS 1  // 0: a variant build with the identity workgroup -> env block map, for A/B runs
+#endif
 #ifndef EMEI_SPLIT_LAUNCH
 #define EMEI_SPLIT_LAUNCH 1  // 0: a variant build without the split of large HBM-bound launches, for A/B runs
 #endif
@@ -559,9 +569,15 @@ static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t
             if (grid.x > round && grid.x <= Env::kSplitMaxRounds * round) per_launch = round;
         }
         RolloutArgs<Env> b = a;
+#ifdef EMEI_XCD_ALWAYS  // experiment: the XCD-contiguous map at every size
+        const bool big = true;
+#else
+        const bool big = grid.x > (unsigned)device_cus();  // more than one wave per SIMD
+#endif
         for (unsigned first = 0; first < grid.x; first += per_launch) {
             b.first_block = first;
             const dim3 g(min(per_launch, grid.x - first));
+            b.xcd_contiguous = EMEI_XCD_CONTIGUOUS != 0 && Env::kXcdContiguous && big && g.x % 8 == 0;
             if (a.freq_rate == 1)
                 hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), g, dim3(kBlock), 0, stream, b);
             else
@@ -604,7 +620,7 @@ static int launch_env(const PendLaunch& L) {
     a.obs_f64 = L.op == PEND_OP_ROLLOUT ? L.obs_f64 : nullptr;
     a.host_flag = L.op == PEND_OP_ROLLOUT ? L.host_flag : nullptr;
     a.flag_value = L.flag_value;
-    a.first_block = 0;
+    a.first_block = 0, a.xcd_contiguous = 0;
     dim3 grid((unsigned)((L.n + kBlock - 1) / kBlock));
     switch (L.op) {
         case PEND_OP_ROLLOUT: {
