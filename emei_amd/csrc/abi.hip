@@ -279,8 +279,9 @@ extern "C" EMEI_API int emei_create(const emei_config* cfg, emei_env** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->cap_hits, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->cap_hits, 0, sizeof(unsigned long long));
     if (e == hipSuccess && steps_as_body(*cfg)) {
-        e = hipMalloc((void**)&h->work, (2 + n_words) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(h->work, 0, (2 + n_words) * sizeof(uint32_t));
+        // (2 + waves words of the queue; a second `waves` words are scratch of probe builds: body_kernels.h, EMEI_CLOCK_HIST_CORR)
+        e = hipMalloc((void**)&h->work, (2 + 2 * n_words) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(h->work, 0, (2 + 2 * n_words) * sizeof(uint32_t));
     }
     if (e == hipSuccess) e = hipMemset(h->done_mask, 0, n_words * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->steps, 0, n * sizeof(int32_t));

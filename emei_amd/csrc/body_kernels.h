@@ -527,6 +527,22 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_store(a.work + WorkQueue::kProgress + blk, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#if defined(EMEI_CLOCK_PROBE) && defined(EMEI_CLOCK_HIST_CORR)
+    // probe builds: how well does the time per step of a wave's previous item predict that of this one?  (slots 0-5: n, sum x, sum y,
+    // sum xy, sum xx, sum yy of ticks per step; x = previous item of the same env-wave, y = this one; tools/tail_probe.py --corr)
+    if constexpr (kQueue) {
+        const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - clock_probe_.r0) / (unsigned long long)(t_end - t_begin);
+        uint32_t* const slot = a.work + WorkQueue::kProgress + a.n_waves + blk;
+        const unsigned long long prev = *slot;
+        if (lane == 0) {
+            if (chunk > 0 && prev > 0) {
+                atomicAdd(&g_debug_stats[0], 1ull), atomicAdd(&g_debug_stats[1], prev), atomicAdd(&g_debug_stats[2], d);
+                atomicAdd(&g_debug_stats[3], prev * d), atomicAdd(&g_debug_stats[4], prev * prev), atomicAdd(&g_debug_stats[5], d * d);
+            }
+            *slot = (uint32_t)d;
+        }
+    }
+#endif
     EMEI_CLOCK_END();
     if constexpr (!kQueue) break;
     }  // item loop

@@ -47,6 +47,8 @@ struct ClockProbe {
             // histogram of lifetimes in EMEI_CLOCK_BIN_TICKS bins (slots 0-15; tools/pend_span.py): are the waves of a SIMD served fairly?
 #ifdef EMEI_CLOCK_HIST_WAVEID  // ... or of the waves' slot ids on their SIMD (HW_REG_HW_ID bits [3:0])
             atomicAdd(&g_debug_stats[__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 15u], 1ull);
+#elif defined(EMEI_CLOCK_HIST_CORR)  // slots 0-5 belong to body_kernels.h's item-to-item correlation
+            (void)0;
 #elif defined(EMEI_CLOCK_HIST_XCC)  // ... or lifetimes per XCD: slots 0-7 ticks, 8-15 waves (HW_REG_XCC_ID = 20, bits [3:0])
             {
                 const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;

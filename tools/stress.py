@@ -18,6 +18,7 @@ big = len(sys.argv) > 2 and sys.argv[2] == "big"  # full-size shards and longer 
 rng = np.random.default_rng(12345)
 names = sorted(L.ENV_IDS)
 t0, cases = time.time(), 0
+last_print = t0
 while time.time() - t0 < budget:
     name = names[rng.integers(len(names))]
     classic = name.startswith("CartPole")
@@ -61,5 +62,8 @@ while time.time() - t0 < budget:
     for e in engs:
         e.close()
     cases += 1
+    if time.time() - last_print > 60:  # a long silent GPU run is taken for a hang by the job runner
+        last_print = time.time()
+        print(f"... {cases} cases, {time.time() - t0:.0f} s", flush=True)
 torch.cuda.synchronize()
 print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s")

@@ -18,7 +18,7 @@ sys.path.insert(0, ".")
 from emei_amd import _lib  # noqa: E402
 from emei_amd.sharding import ShardedRollout  # noqa: E402
 
-chunks = [int(a) for a in sys.argv[1:]] or [-1, 25, 10, 7, 5, 4, 2]
+chunks = [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [-1, 25, 10, 7, 5, 4, 2]
 CASES = (("HalfCheetahRunning", 131072, 100, 4, 0.002, "euler", "body_tu_ch_f64"), ("HopperRunning", 131072, 100, 4, 0.002, "rk4", "body_tu_hp_f64"),
          ("HopperRunning", 131072, 100, 4, 0.002, "euler", "body_tu_hp_f64"))
 simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
@@ -49,6 +49,10 @@ for env, n, T, fr, dt, integ, tu in CASES:
             line += f"  longest lifetime {int(out[23]) / 100.0:.1f} us"
             if int(out[21]):
                 line += f"  mean worker exit {(end - int(out[22]) / int(out[21])) / 100.0:.1f} us before the last end"
+            if "--corr" in sys.argv and int(out[0]):  # a -DEMEI_CLOCK_HIST_CORR build
+                nn, sx, sy, sxy, sxx, syy = (float(int(out[k])) for k in range(6))
+                cov, vx, vy = sxy / nn - sx * sy / nn**2, sxx / nn - (sx / nn) ** 2, syy / nn - (sy / nn) ** 2
+                line += f"  ticks/step of an item vs the same wave's previous item: r = {cov / (vx * vy) ** 0.5:.3f} (mean {sy / nn:.0f}, sd {vy ** 0.5:.0f})"
             if workers:
                 line += f"  workers with an item {workers}, the last began its first item {(last_first - first) / 100.0:.1f} us into the launch"
         print(line + f"  faults {sr.engine.rollout_faults()}", flush=True)
