@@ -196,6 +196,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     const int64_t i = (int64_t)(env_block + a.first_block) * kBlock + threadIdx.x;  // n % 64 == 0: whole waves only
 #endif
     if (i >= a.n) return;
+#if defined(EMEI_XCD_ONLY)  // experiment (timing only, results of the skipped envs are not produced): only the workgroups of the XCDs in this bit mask work
+    if (!(((unsigned)EMEI_XCD_ONLY >> (blockIdx.x & 7u)) & 1u)) return;
+#endif
     EMEI_CLOCK_BEGIN();
     const int64_t n = a.n;
     const uint32_t li = (uint32_t)i, i0 = li - (uint32_t)lane;

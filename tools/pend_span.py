@@ -6,6 +6,7 @@ from emei_amd.sharding import ShardedRollout
 M64=(1<<64)-1
 for env, n, T, fr, tu in (("BoundaryInvertedPendulumSwingUp", 262144, 250, 4, "pend_tu_ip3_f64"), ("BoundaryInvertedPendulumBalancing", 262144, 250, 4, "pend_tu_ip1_f64"),
                           ("BoundaryInvertedPendulumBalancing", 196608, 250, 4, "pend_tu_ip1_f64"), ("CartPoleSwingUp", 65536, 1000, 1, "pend_tu_cp0_f64"), ("CartPoleSwingUp", 131072, 1000, 1, "pend_tu_cp0_f64")):
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] not in env: continue
     sr = ShardedRollout(env, n, T, freq_rate=fr, real_time_scale=0.02)
     sr.make_synthetic_inputs()
     for _ in range(300): sr.run_pass()  # ~0.2 s: the clocks settle (bench.py's settle phase)
