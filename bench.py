@@ -223,6 +223,45 @@ def rccl_summary(path, world):
     return info
 
 
+class ExtrasGuard:
+    """Deadline for the measurements that FOLLOW the timed region at N > 1.  They run collectives of their own (the other exchange form has
+    never run on a real multi-GPU node); if one of them hangs, every rank's timer fires at about the same moment (they were started after a
+    barrier): rank 0 prints the line it already has, marked `extras_timed_out`, and each rank leaves with os._exit — no collective can be
+    waited for any more.  An exception in an extra is recorded under `extras_error` instead of losing the line."""
+
+    def __init__(self, out, rank, seconds):
+        import threading
+
+        self.out, self.rank, self.seconds = out, rank, seconds
+        self.lock, self.printed = threading.Lock(), False
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+
+    def start(self):
+        self.timer.start()
+        return self
+
+    def _fire(self):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0:
+                line = dict(self.out)
+                line["extras_timed_out"] = f"the measurements after the timed region did not finish within {self.seconds:.0f} s; those present are complete"
+                print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    def finish(self):
+        """True if the caller should print the line (the timer has not fired)."""
+        self.timer.cancel()
+        with self.lock:
+            if self.printed:
+                return False
+            self.printed = True
+            return True
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as children of torch.distributed.run.
     This process never imports torch and never touches a GPU; it relays rank 0's JSON line and the launcher's status."""
@@ -291,6 +330,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=60.0, help="untimed clock-settle phase before the warm-up passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-profiler-env", action="store_true", help="self-launch N > 1 ranks even though a profiler preload is detected")
+    ap.add_argument("--extras-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the additional measurements after the timed region (compute_only, value_final_gather, the other exchange form) may take "
+                         "before rank 0 prints the line without them and every rank exits (a hang there must not cost the run its headline number)")
     ap.add_argument("--no-rccl-info", action="store_true", help="do not switch on NCCL_DEBUG=INFO (N > 1, RCCL: the line reports what RCCL chose)")
     ap.add_argument("--per-step-api", action="store_true", help="also time one launch per env-step (emei_step)")
     a = ap.parse_args()
@@ -479,81 +521,100 @@ def main():
                        "note": "whole-pass average: the all-gathers overlap the rollout launches"
                                + ("; with --gather per_chunk / per_step every rank receives the whole observation return of its peers, "
                                   "so N > 1 is bound by xGMI by design, not by the rollout kernel" if gather != "final" else "")}
+    guard = None
     if world > 1:
-        # What the rollout kernels alone sustain, per rank and summed: N envs x the steps of one launch / that launch's duration,
-        # measured on every rank with no collective between the launches (timed_launches_ms).  Beside `value` it separates how
-        # the KERNEL scales with N from what the chosen observation exchange costs.
-        mine = N * T_launch / (kernel_ms * 1e-3)
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
-        out["compute_only"] = {"value": float(sum(per_rank)), "unit": "env-steps/s", "per_rank": [float(v) for v in per_rank],
-                               "what": "sum over ranks of envs_per_gpu x steps per launch / rollout-kernel launch duration (HIP events "
-                                       "around back-to-back launches, no collective in the span)"}
-        if gather != "final":
-            # ... and the same job with only the LAST observation of each pass exchanged (--gather final), timed in this run under
-            # the same barrier / max-over-ranks rule: `value` keeps the default mode's number
-            sf = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
+        # everything below runs collectives of its own AFTER the timed region: under a deadline, so that a hang costs the extras, not the line
+        guard = ExtrasGuard(out, rank, a.extras_timeout).start()
+        try:
+            if os.environ.get("EMEI_BENCH_TEST_EXTRAS") == "hang":  # test hooks (tests/test_gpu_bench_contract.py): a collective that never returns ...
+                time.sleep(1e6)
+            if os.environ.get("EMEI_BENCH_TEST_EXTRAS") == "raise":  # ... and one that fails
+                raise RuntimeError("EMEI_BENCH_TEST_EXTRAS=raise")
+            # What the rollout kernels alone sustain, per rank and summed: N envs x the steps of one launch / that launch's duration,
+            # measured on every rank with no collective between the launches (timed_launches_ms).  Beside `value` it separates how
+            # the KERNEL scales with N from what the chosen observation exchange costs.
+            mine = N * T_launch / (kernel_ms * 1e-3)
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            out["compute_only"] = {"value": float(sum(per_rank)), "unit": "env-steps/s", "per_rank": [float(v) for v in per_rank],
+                                   "what": "sum over ranks of envs_per_gpu x steps per launch / rollout-kernel launch duration (HIP events "
+                                           "around back-to-back launches, no collective in the span)"}
+            if gather != "final":
+                # ... and the same job with only the LAST observation of each pass exchanged (--gather final), timed in this run under
+                # the same barrier / max-over-ranks rule: `value` keeps the default mode's number
+                sf = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
+                                    world=world, device=local_rank, seed=0, integrator=a.integrator or w.get("integrator", "euler"),
+                                    gather="final", solver=a.solver)
+                sf.make_synthetic_inputs()
+                for _ in range(max(a.warmup, 2)):
+                    sf.run_pass()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                for _ in range(a.steps):
+                    sf.run_pass()
+                sf.wait_gathers()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tf = torch.tensor([time.perf_counter() - tf], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+                out["value_final_gather"] = {"value": total_env_steps / float(tf.item()), "unit": "env-steps/s",
+                                             "ms_per_step": float(tf.item()) / a.steps * 1e3, "gather": "final",
+                                             "what": "the same job, same run, exchanging only the last [n, obs_dim] observation of each pass"}
+                sf.engine.close()
+                del sf
+            # ... and the same job with the OTHER form of the exchange (`--exchange direct`: 1-hop point-to-point transfers to and from
+            # every peer, the shape of the xGMI mesh; or the collective when direct is the run's own), same gather mode, same barrier /
+            # max-over-ranks rule: one 8-GPU run answers which of the two the node prefers
+            other = "direct" if a.exchange == "collective" else "collective"
+            so = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
                                 world=world, device=local_rank, seed=0, integrator=a.integrator or w.get("integrator", "euler"),
-                                gather="final", solver=a.solver)
-            sf.make_synthetic_inputs()
+                                gather=gather, chunk=chunk, solver=a.solver, exchange_algo=other, rollout_chunk_steps=a.rollout_chunk_steps)
+            so.make_synthetic_inputs()
             for _ in range(max(a.warmup, 2)):
-                sf.run_pass()
+                so.run_pass()
+            so.wait_gathers()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-            tf = time.perf_counter()
+            to = time.perf_counter()
             for _ in range(a.steps):
-                sf.run_pass()
-            sf.wait_gathers()
+                so.run_pass()
+            so.wait_gathers()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-            tf = torch.tensor([time.perf_counter() - tf], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-            out["value_final_gather"] = {"value": total_env_steps / float(tf.item()), "unit": "env-steps/s",
-                                         "ms_per_step": float(tf.item()) / a.steps * 1e3, "gather": "final",
-                                         "what": "the same job, same run, exchanging only the last [n, obs_dim] observation of each pass"}
-            sf.engine.close()
-            del sf
-        # ... and the same job with the OTHER form of the exchange (`--exchange direct`: 1-hop point-to-point transfers to and from
-        # every peer, the shape of the xGMI mesh; or the collective when direct is the run's own), same gather mode, same barrier /
-        # max-over-ranks rule: one 8-GPU run answers which of the two the node prefers
-        other = "direct" if a.exchange == "collective" else "collective"
-        so = ShardedRollout(env, N, T, freq_rate=w["freq_rate"], real_time_scale=w["dt"], precision=a.precision, rank=rank,
-                            world=world, device=local_rank, seed=0, integrator=a.integrator or w.get("integrator", "euler"),
-                            gather=gather, chunk=chunk, solver=a.solver, exchange_algo=other, rollout_chunk_steps=a.rollout_chunk_steps)
-        so.make_synthetic_inputs()
-        for _ in range(max(a.warmup, 2)):
-            so.run_pass()
-        so.wait_gathers()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        to = time.perf_counter()
-        for _ in range(a.steps):
-            so.run_pass()
-        so.wait_gathers()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        to = torch.tensor([time.perf_counter() - to], dtype=torch.float64, device="cuda")
-        dist.all_reduce(to, op=dist.ReduceOp.MAX)
-        gbo = so.gathered_bytes_per_pass
-        out["value_direct_exchange" if other == "direct" else "value_collective_exchange"] = {
-            "value": total_env_steps / float(to.item()), "unit": "env-steps/s", "ms_per_step": float(to.item()) / a.steps * 1e3,
-            "exchange": other, "gather": gather, "xgmi_inbound_gbs": gbo * a.steps / float(to.item()) / 1e9,
-            "what": f"the same job, same run, same gather mode, the observation return as {'batched point-to-point transfers (sharding._allgather_direct)' if other == 'direct' else 'the backend all-gather'}"}
-        so.engine.close()
-        del so
-        if rccl_log:
-            out["rccl"] = rccl_summary(rccl_log, world)
+            to = torch.tensor([time.perf_counter() - to], dtype=torch.float64, device="cuda")
+            dist.all_reduce(to, op=dist.ReduceOp.MAX)
+            gbo = so.gathered_bytes_per_pass
+            out["value_direct_exchange" if other == "direct" else "value_collective_exchange"] = {
+                "value": total_env_steps / float(to.item()), "unit": "env-steps/s", "ms_per_step": float(to.item()) / a.steps * 1e3,
+                "exchange": other, "gather": gather, "xgmi_inbound_gbs": gbo * a.steps / float(to.item()) / 1e9,
+                "what": f"the same job, same run, same gather mode, the observation return as {'batched point-to-point transfers (sharding._allgather_direct)' if other == 'direct' else 'the backend all-gather'}"}
+            so.engine.close()
+            del so
+            if rccl_log:
+                out["rccl"] = rccl_summary(rccl_log, world)
+        except Exception as e:  # recorded, not fatal: the headline number is already measured
+            out["extras_error"] = repr(e)[:500]
     if a.per_step_api and rank == 0:
         out["per_step_api"] = sr.time_per_step_api()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(env, N, w["freq_rate"], w["dt"], a.integrator or w.get("integrator", "euler"), a.solver)
+    if guard is not None and not guard.finish():
+        time.sleep(30)  # the deadline fired: its thread prints rank 0's line and ends the process
+        return
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
+        if "extras_error" in out:  # ranks may be out of step after an error: do not wait for a clean teardown for ever
+            import threading
+
+            t = threading.Timer(60.0, os._exit, (0,))
+            t.daemon = True
+            t.start()
         dist.destroy_process_group()
 
 

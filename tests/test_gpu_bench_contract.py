@@ -130,6 +130,23 @@ def test_collective_is_the_other_exchange_when_direct_is_the_runs_own():
     assert "value_direct_exchange" not in j
 
 
+@pytest.mark.parametrize("how", ["hang", "raise"])
+def test_a_hang_or_an_error_after_the_timed_region_does_not_cost_the_line(how):
+    """The measurements that follow the timed region at N > 1 (compute_only, value_final_gather, the other exchange form) run under a
+    deadline (bench.ExtrasGuard): a hang there leaves the headline number in the line, marked; an exception is recorded."""
+    e = dict(os.environ, EMEI_BENCH_SHARE_GPU="1", EMEI_BENCH_BACKEND="gloo", EMEI_BENCH_TEST_EXTRAS=how)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "16384", "--extras-timeout", "5"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "xgmi" in j and "compute_only" not in j
+    assert ("extras_timed_out" in j) == (how == "hang") and ("extras_error" in j) == (how == "raise")
+
+
 def test_a_failing_rank_fails_the_self_launched_bench():
     """exit status of the launcher is relayed: an impossible workload size makes every rank raise"""
     e = dict(os.environ, EMEI_BENCH_SHARE_GPU="1", EMEI_BENCH_BACKEND="gloo")
