@@ -314,9 +314,11 @@ def main():
     ap.add_argument("--gather", default=None, choices=["final", "per_chunk", "per_step"],
                     help="what the observation return exchanges across ranks (default: per_chunk when --gpus > 1, final otherwise)")
     ap.add_argument("--chunk", type=int, default=125, help="steps per launch / per all-gather with --gather per_chunk")
-    ap.add_argument("--exchange", default="collective", choices=["collective", "direct"],
-                    help="how the observation return crosses ranks: the backend's all-gather, or 1-hop transfers to and from every "
-                         "peer at once (the xGMI mesh has a link per peer)")
+    ap.add_argument("--exchange", default="collective", choices=["collective", "direct", "peer_write"],
+                    help="how the observation return crosses ranks: the backend's all-gather, 1-hop transfers to and from every "
+                         "peer at once (the xGMI mesh has a link per peer), or no collective at all: the rollout kernel writes every "
+                         "observation row into hipIpc-mapped buffers of every rank (CartPole workloads, --gather per_chunk; "
+                         "opt-in: it has never run on a multi-GPU node)")
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--precision", default="ref", choices=["ref", "f32"])
     ap.add_argument("--integrator", default=None, choices=["euler", "semi_implicit_euler", "rk4"],
@@ -476,7 +478,8 @@ def main():
                    "obs_allgather": ({"final": "last [n,obs_dim] observation of each pass",
                                       "per_chunk": f"the whole [T,n,obs_dim] observation return, one all-gather per {sr.chunk}-step chunk",
                                       "per_step": "the [n,obs_dim] observation of every env-step, one all-gather per step"}[gather]
-                                     + " over RCCL, on a dedicated stream under the following launches") if world > 1 else "n/a (1 GPU)"},
+                                     + (" over RCCL, on a dedicated stream under the following launches" if a.exchange != "peer_write" else
+                                        " — here WITHOUT a collective: written by the rollout kernel into every rank's hipIpc-mapped buffer, one host barrier per chunk")) if world > 1 else "n/a (1 GPU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (f"{prof.get('profile', 'profiles/')} via profiles/traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE "
@@ -608,6 +611,8 @@ def main():
         return
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1 and a.exchange == "peer_write":
+        sr.close()  # peer-mapped buffers: every rank unmaps before the owners free them
     if dist:
         if "extras_error" in out:  # ranks may be out of step after an error: do not wait for a clean teardown for ever
             import threading

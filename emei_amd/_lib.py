@@ -31,15 +31,18 @@ ACT_U8, ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2, 3
 FLAG_AUTO_RESET = 1
 DONE_TERMINAL, DONE_TRUNCATED = 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
-ABI_VERSION = 6
+ABI_VERSION = 7
 IO_F32, IO_F64 = 0, 1  # enum emei_io_dtype
 REWARD_BATCH_CTRL_COST = 1  # flag of emei_reward_io (half_cheetah.py:61 / hopper.py:98: np.sum over the whole batch)
 # enum emei_kernel_id (emei_last_rollout_kernel)
 KERNEL_NAMES = {0: "none", 1: "pend_rollout_staged_kernel<freq1>", 2: "pend_rollout_staged_kernel", 3: "pend_rollout_kernel<full>",
                 4: "pend_rollout_kernel", 5: "body_rollout_kernel", 6: "body_rollout_kernel<rk4>",
-                7: "body_rollout_kernel (chunked work items)", 8: "body_rollout_kernel<rk4> (chunked work items)"}
+                7: "body_rollout_kernel (chunked work items)", 8: "body_rollout_kernel<rk4> (chunked work items)",
+                9: "pend_rollout_staged_peers_kernel<freq1>", 10: "pend_rollout_staged_peers_kernel"}
 KERNEL_PEND_STAGED_FREQ1, KERNEL_PEND_STAGED, KERNEL_PEND_GENERIC_FULL, KERNEL_PEND_GENERIC, KERNEL_BODY, KERNEL_BODY_RK4 = 1, 2, 3, 4, 5, 6
 KERNEL_BODY_CHUNKED, KERNEL_BODY_RK4_CHUNKED = 7, 8
+KERNEL_PEND_STAGED_PEERS_FREQ1, KERNEL_PEND_STAGED_PEERS = 9, 10
+MAX_OBS_PEERS = 8  # EMEI_MAX_OBS_PEERS
 # enum emei_ode_method: `method` of ODE_approximation (base_control.py:133-173), classic control only
 ODE_METHODS = {"euler": 0, "rk4": 1}
 NEXT_OBS_ODE_RK4 = 0x100  # flag on emei_next_obs_io's `integrator`
@@ -101,6 +104,11 @@ SYMBOLS = {
     "emei_get_solver_cap_hits": (C.c_int, [_vp, _vp, _vp]),
     "emei_get_rollout_faults": (C.c_int, [_vp, _vp, _vp]),
     "emei_last_rollout_kernel": (C.c_int, [_vp]),
+    "emei_set_obs_peers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _i64, _i64]),
+    "emei_peer_buffer_create": (C.c_int, [C.c_int, _u64, C.POINTER(_vp), _vp]),
+    "emei_peer_buffer_open": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "emei_peer_buffer_close": (C.c_int, [C.c_int, _vp]),
+    "emei_peer_buffer_destroy": (C.c_int, [C.c_int, _vp]),
     "emei_set_state": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "emei_get_state": (C.c_int, [_vp, _vp, _vp]),
     "emei_get_obs": (C.c_int, [_vp, _vp, _vp]),

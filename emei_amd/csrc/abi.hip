@@ -39,6 +39,7 @@ struct emei_env {
     uint32_t flag_seq = 0;          // ... and the value the next launch stores into it
     PendParams pend;
     const void* trig;
+    ObsPeers peers;  // emei_set_obs_peers
 };
 
 static thread_local char g_err[512] = "";
@@ -354,6 +355,7 @@ static PendLaunch pend_base(emei_env* h, void* stream) {
     L.p = h->pend;
     L.trig = h->trig;
     L.stream = (hipStream_t)stream;
+    L.peers = h->peers;
     return L;
 }
 
@@ -498,6 +500,88 @@ extern "C" EMEI_API int emei_get_rollout_faults(emei_env* h, uint64_t* count_out
     return EMEI_OK;
 }
 
+extern "C" EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset) {
+    if (!h) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: null handle");
+    if (n_peers == 0) {
+        h->peers = ObsPeers();
+        return EMEI_OK;
+    }
+    if (n_peers < 0 || n_peers > EMEI_MAX_OBS_PEERS) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: n_peers=%d outside 0..%d", n_peers, EMEI_MAX_OBS_PEERS);
+    if (!peer_obs) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: null pointer list");
+    if (col_offset < 0 || row_envs < col_offset + h->cfg.n_envs)
+        return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: columns [%lld, %lld) do not fit a row of %lld envs", (long long)col_offset,
+                    (long long)(col_offset + h->cfg.n_envs), (long long)row_envs);
+    if (steps_as_body(h->cfg) || h->obs_dim != 4 || h->cfg.env_id > EMEI_CARTPOLE_BALANCING)
+        return fail(EMEI_ERR_UNSUPPORTED, "emei_set_obs_peers: built for the CartPole family (env_id %d)", h->cfg.env_id);
+    ObsPeers P;
+    for (int p = 0; p < n_peers; ++p) {
+        if (!peer_obs[p] || ((uintptr_t)peer_obs[p] & 15u)) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: peer %d is null or not 16-byte aligned", p);
+        P.obs[p] = peer_obs[p];
+    }
+    P.row_envs = row_envs, P.col = col_offset, P.count = n_peers;
+    h->peers = P;
+    return EMEI_OK;
+}
+
+// Device memory another process of this node can map (hipIpc): see include/emei_hip.h
+static_assert(sizeof(hipIpcMemHandle_t) == sizeof(emei_ipc_handle), "hipIpcMemHandle_t is 64 opaque bytes");
+struct DeviceScope {  // the calls below act on the caller's device and leave the current device as they found it
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceScope(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" EMEI_API int emei_peer_buffer_create(int device, uint64_t bytes, void** dev_ptr_out, emei_ipc_handle* handle_out) {
+    if (!dev_ptr_out || !handle_out || bytes == 0) return fail(EMEI_ERR_INVALID, "emei_peer_buffer_create: bad argument");
+    DeviceScope scope(device);
+    HIP_TRY(scope.err);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    hipIpcMemHandle_t hnd;
+    hipError_t e = hipIpcGetMemHandle(&hnd, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(EMEI_ERR_HIP, "hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the host driver only has dmabuf IPC)", hipGetErrorString(e));
+    }
+    memcpy(handle_out->bytes, &hnd, sizeof(hnd));
+    *dev_ptr_out = p;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_peer_buffer_open(int device, const emei_ipc_handle* handle, void** dev_ptr_out) {
+    if (!handle || !dev_ptr_out) return fail(EMEI_ERR_INVALID, "emei_peer_buffer_open: null argument");
+    DeviceScope scope(device);
+    HIP_TRY(scope.err);
+    hipIpcMemHandle_t hnd;
+    memcpy(&hnd, handle->bytes, sizeof(hnd));
+    void* p = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess));
+    *dev_ptr_out = p;
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_peer_buffer_close(int device, void* dev_ptr) {
+    if (!dev_ptr) return fail(EMEI_ERR_INVALID, "emei_peer_buffer_close: null pointer");
+    DeviceScope scope(device);
+    HIP_TRY(scope.err);
+    HIP_TRY(hipIpcCloseMemHandle(dev_ptr));
+    return EMEI_OK;
+}
+
+extern "C" EMEI_API int emei_peer_buffer_destroy(int device, void* dev_ptr) {
+    if (!dev_ptr) return fail(EMEI_ERR_INVALID, "emei_peer_buffer_destroy: null pointer");
+    DeviceScope scope(device);
+    HIP_TRY(scope.err);
+    HIP_TRY(hipFree(dev_ptr));
+    return EMEI_OK;
+}
+
 static int check_action_dtype(const emei_env* h, int action_dtype) {
     if (action_dtype < EMEI_ACT_U8 || action_dtype > EMEI_ACT_F32) return fail(EMEI_ERR_INVALID, "bad action_dtype %d", action_dtype);
     int od, ad, sd;
@@ -530,7 +614,13 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
         L.flags = flags;
         L.selected = &h->last_kernel;
         rc = pend_launch(L);
+        if (rc == EMEI_ERR_UNSUPPORTED && h->peers.count > 0)
+            return fail(rc, "emei_rollout: observation peers are set (emei_set_obs_peers), which only the staged kernel of the CartPole family "
+                            "serves: n_envs a multiple of 64, n_steps >= 16, all three outputs, 16-byte aligned buffers (n_envs=%lld, n_steps=%d)",
+                        (long long)h->cfg.n_envs, n_steps);
     } else {
+        if (h->peers.count > 0)
+            return fail(EMEI_ERR_UNSUPPORTED, "emei_rollout: observation peers are set (emei_set_obs_peers), which the body kernels do not serve");
         BodyLaunch L = body_base(h, stream);
         L.op = BODY_OP_ROLLOUT;
         L.actions = actions;

@@ -9,6 +9,13 @@ namespace emei {
 
 enum PendOp { PEND_OP_ROLLOUT = 0, PEND_OP_RESET, PEND_OP_GET_OBS, PEND_OP_REWARD_TERMINAL, PEND_OP_NEXT_OBS, PEND_OP_INIT_OBS };
 
+// emei_set_obs_peers: the gathered buffers the staged rollout kernel also writes every observation row to
+struct ObsPeers {
+    void* obs[EMEI_MAX_OBS_PEERS] = {};
+    int64_t row_envs = 0, col = 0;
+    int count = 0;
+};
+
 struct PendLaunch {
     int op = PEND_OP_ROLLOUT;
     int env_id = 0, precision = 0;
@@ -39,6 +46,7 @@ struct PendLaunch {
     // memory, system scope, after everything else it wrote)
     uint32_t* host_flag = nullptr;
     uint32_t flag_value = 0;
+    ObsPeers peers;  // PEND_OP_ROLLOUT: count > 0 -> the staged peers kernel or EMEI_ERR_UNSUPPORTED
 };
 
 // pendulum_kernels.hip

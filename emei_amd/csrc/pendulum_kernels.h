@@ -37,6 +37,16 @@ struct RolloutArgs {
     uint32_t first_block;  // staged kernel: a launch may cover the blocks [first_block, first_block + gridDim.x) of the shard (launch_rollout_full)
 };
 
+// emei_set_obs_peers (multi-GPU observation return by peer writes): where the staged rollout kernel ALSO stores every step's
+// observation — up to EMEI_MAX_OBS_PEERS gathered buffers [n_steps, row_envs, 4] float32 (hipIpc-mapped memory of the other ranks, and
+// this rank's own), this shard's envs at columns [col, col + n).  A kernel argument of its own, so that the kernel without peers keeps
+// its arguments (and its code) unchanged.
+struct PeerObs {
+    float4* obs[EMEI_MAX_OBS_PEERS];
+    int64_t row_envs, col;
+    uint32_t count;
+};
+
 // emei_step (n_steps = 1) and emei_rollout (n_steps = T): base_control.py:61-83 /
 // mujoco_env.py:157-167 for every env of the shard, T times, without leaving the registers.
 // FULL = all three outputs are non-null: the stores are then unconditional, which lets the compiler
@@ -164,9 +174,9 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 template <typename ActT>
 constexpr int stage_steps() { return sizeof(ActT) == 1 ? 16 : 8; }
 
-template <class Env, typename ActT, bool FREQ1>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env::kMinWavesPerEU)))
-    pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
+// The body of the two staged kernels below (PEERS: with the peer stores of emei_set_obs_peers).
+template <class Env, typename ActT, bool FREQ1, bool PEERS>
+__device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, const PeerObs& peers) {
     using R = typename Env::real;
     constexpr int kWavesPerBlock = kBlock / kWave;
     constexpr int kStage = stage_steps<ActT>();
@@ -338,6 +348,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
         }
 #endif
     };
+    // PEERS: the observation row of step t also goes to every peer's gathered buffer (remote stores over xGMI: the launch then runs at the
+    // links' rate, which is what the separate all-gather would take).  They are further stores AFTER the tile's loads in the shared in-order
+    // counter, so the retire wait below (at most kStage operations left in flight) still covers every load.
+    auto store_obs_peers = [&](int t, const float4& v) __attribute__((always_inline)) {
+        if constexpr (PEERS) {
+            const int64_t at = (int64_t)t * peers.row_envs + peers.col + li;
+            for (uint32_t p = 0; p < peers.count; ++p) peers.obs[p][at] = v;
+        }
+    };
     EMEI_LOAD_TILE(0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t0 = 0, buf = 0;
@@ -371,7 +390,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
                 act_cur = act_l[min(j + 1, kStage - 1) * kWave + lane];
                 R o[4], rew;
                 advance(act_now, o, rew);
-                (a.obs_out + (int64_t)(t0 + j) * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+                const float4 obs4 = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+                (a.obs_out + (int64_t)(t0 + j) * n)[li] = obs4;
+                store_obs_peers(t0 + j, obs4);
                 if (q == 0) {  // rows staged during the previous group: their LDS read has landed
                     if (t0 + j > 0) store_rew_rows(t0 + j - 4, rew_pend);
                     if (g == 0 && t0 > 0) store_done_rows(t0 - kStage, done_pend);
@@ -405,7 +426,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     for (int t = t0; t < a.n_steps; ++t) {
         R o[4], rew;
         advance((actions + (int64_t)t * n)[li], o, rew);
-        (a.obs_out + (int64_t)t * n)[li] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        const float4 obs4 = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        (a.obs_out + (int64_t)t * n)[li] = obs4;
+        store_obs_peers(t, obs4);
         (a.reward_out + (int64_t)t * n)[li] = (float)rew;
         (a.done_out + (int64_t)t * n)[li] = (uint8_t)done;
         maybe_reset();
@@ -419,6 +442,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env
     if (lane == 0) a.done_mask[i / kWave] = m;
     EMEI_CLOCK_END();
 #undef EMEI_LOAD_TILE
+}
+
+template <class Env, typename ActT, bool FREQ1>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env::kMinWavesPerEU)))
+    pend_rollout_staged_kernel(const RolloutArgs<Env> a) {
+    pend_rollout_staged<Env, ActT, FREQ1, false>(a, PeerObs{});
+}
+
+// ... and with the peer stores (emei_set_obs_peers; Env::kPeerWrite: the CartPole family, BASELINE configs[4]'s env)
+template <class Env, typename ActT, bool FREQ1>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Env::kMinWavesPerEU)))
+    pend_rollout_staged_peers_kernel(const RolloutArgs<Env> a, const PeerObs peers) {
+    pend_rollout_staged<Env, ActT, FREQ1, true>(a, peers);
 }
 
 // Env.reset on the device
@@ -555,9 +591,19 @@ static inline int device_cus() {
     return cus[dev];
 }
 
+// Returns the enum emei_kernel_id launched, or a negative EMEI_ERR_* (peers set on a path that has no peer stores).
 template <class Env, typename ActT>
-static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream) {
+static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t stream, const ObsPeers& peers) {
     const bool full = a.obs_out && a.reward_out && a.done_out;
+    PeerObs po{};
+    if (peers.count > 0) {
+        if (!Env::kPeerWrite) return EMEI_ERR_UNSUPPORTED;
+        for (int p = 0; p < peers.count; ++p) {
+            if (!aligned16(peers.obs[p])) return EMEI_ERR_UNSUPPORTED;
+            po.obs[p] = (float4*)peers.obs[p];
+        }
+        po.row_envs = peers.row_envs, po.col = peers.col, po.count = (uint32_t)peers.count;
+    }
     if (full && a.n_steps >= stage_steps<ActT>() && a.n % kWave == 0 && aligned16(a.actions) && aligned16(a.obs_out) &&
         aligned16(a.reward_out) && aligned16(a.done_out))
     {
@@ -581,13 +627,24 @@ static int launch_rollout_full(const RolloutArgs<Env>& a, dim3 grid, hipStream_t
             b.first_block = first;
             const dim3 g(min(per_launch, grid.x - first));
             b.xcd_contiguous = EMEI_XCD_CONTIGUOUS != 0 && Env::kXcdContiguous && big && g.x % 8 == 0;
+            if constexpr (Env::kPeerWrite) {
+                if (po.count > 0) {
+                    if (a.freq_rate == 1)
+                        hipLaunchKernelGGL((pend_rollout_staged_peers_kernel<Env, ActT, true>), g, dim3(kBlock), 0, stream, b, po);
+                    else
+                        hipLaunchKernelGGL((pend_rollout_staged_peers_kernel<Env, ActT, false>), g, dim3(kBlock), 0, stream, b, po);
+                    continue;
+                }
+            }
             if (a.freq_rate == 1)
                 hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, true>), g, dim3(kBlock), 0, stream, b);
             else
                 hipLaunchKernelGGL((pend_rollout_staged_kernel<Env, ActT, false>), g, dim3(kBlock), 0, stream, b);
         }
+        if (po.count > 0) return a.freq_rate == 1 ? EMEI_KERNEL_PEND_STAGED_PEERS_FREQ1 : EMEI_KERNEL_PEND_STAGED_PEERS;
         return a.freq_rate == 1 ? EMEI_KERNEL_PEND_STAGED_FREQ1 : EMEI_KERNEL_PEND_STAGED;
     }
+    if (po.count > 0) return EMEI_ERR_UNSUPPORTED;  // ragged n, a short horizon, unaligned or missing outputs: the generic kernels have no peer stores
     if (full) {
         hipLaunchKernelGGL((pend_rollout_kernel<Env, ActT, true>), grid, dim3(kBlock), 0, stream, a);
         return EMEI_KERNEL_PEND_GENERIC_FULL;
@@ -630,14 +687,15 @@ static int launch_env(const PendLaunch& L) {
             // discrete envs take uint8/int32/int64 actions, continuous envs float32
             int sel;
             if constexpr (Env::kDiscrete) {
-                if (L.action_dtype == EMEI_ACT_U8) sel = launch_rollout_full<Env, uint8_t>(a, grid, L.stream);
-                else if (L.action_dtype == EMEI_ACT_I32) sel = launch_rollout_full<Env, int32_t>(a, grid, L.stream);
-                else if (L.action_dtype == EMEI_ACT_I64) sel = launch_rollout_full<Env, int64_t>(a, grid, L.stream);
+                if (L.action_dtype == EMEI_ACT_U8) sel = launch_rollout_full<Env, uint8_t>(a, grid, L.stream, L.peers);
+                else if (L.action_dtype == EMEI_ACT_I32) sel = launch_rollout_full<Env, int32_t>(a, grid, L.stream, L.peers);
+                else if (L.action_dtype == EMEI_ACT_I64) sel = launch_rollout_full<Env, int64_t>(a, grid, L.stream, L.peers);
                 else return EMEI_ERR_INVALID;
             } else {
                 if (L.action_dtype != EMEI_ACT_F32) return EMEI_ERR_INVALID;
-                sel = launch_rollout_full<Env, float>(a, grid, L.stream);
+                sel = launch_rollout_full<Env, float>(a, grid, L.stream, L.peers);
             }
+            if (sel < 0) return sel;
             if (L.selected) *L.selected = sel;
             break;
         }

@@ -155,8 +155,20 @@ class Engine:
         L.check(L.lib().emei_get_rollout_faults(self._h, _ptr(out), _stream()))
         return int(out.item())
 
+    def set_obs_peers(self, peers, row_envs, col_offset):
+        """emei_set_obs_peers: from now on every rollout ALSO stores each step's observation row into the gathered buffers `peers`
+        (device pointers as ints, or float32 tensors [rows, row_envs, obs_dim]; at most _lib.MAX_OBS_PEERS), this engine's envs at
+        columns [col_offset, col_offset + n_envs) — the multi-GPU observation return by peer writes (sharding.PeerWriteExchange).
+        An empty list switches it off.  Rollouts the staged CartPole kernel cannot serve then raise instead of skipping the peers."""
+        self._live()
+        ptrs = [int(p.data_ptr()) if torch.is_tensor(p) else int(p) for p in peers]
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        L.check(L.lib().emei_set_obs_peers(self._h, len(ptrs), arr, int(row_envs), int(col_offset)))
+        self._peer_refs = [p for p in peers if torch.is_tensor(p)]  # keep local targets alive while they are written to
+
     def last_kernel(self):
         """enum emei_kernel_id of the kernel the last step / rollout launched (_lib.KERNEL_NAMES)."""
+        self._live()
         return int(L.lib().emei_last_rollout_kernel(self._h))
 
     @_on_device

@@ -18,6 +18,7 @@ def shard_bounds(n_global, rank, world):
 
 
 ALGOS = ("collective", "direct")
+EXCHANGES = ALGOS + ("peer_write",)  # ShardedRollout(exchange_algo=...): the two all-gather forms, or no collective at all (PeerWriteExchange)
 
 
 def _allgather_direct(local_obs, flat, group):
@@ -174,6 +175,182 @@ class ObsExchange:
                 torch.cuda.current_stream().wait_event(ev)
 
 
+class _DeviceArray:
+    """A raw device pointer as torch.as_tensor accepts it (the CUDA array interface, which the ROCm build of torch honours)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class PeerWriteExchange:
+    """The batched observation return WITHOUT a collective ("hipIpc peer writes from the step kernel's epilogue"; C-ABI:
+    emei_set_obs_peers + emei_peer_buffer_*).  Every rank owns two gathered buffers [rows, world * n, obs_dim] float32 (step-major,
+    global env order) in memory its peers map through hipIpc; the rollout kernel of every rank stores each observation row into the
+    current buffer of EVERY rank — its own included — at its columns, while it computes.  Nothing is re-read from HBM and no
+    all-gather follows the launch; 7 x 16 B per env-step leave the GPU over xGMI either way, so the launch runs at the links' rate.
+
+    Ordering (host side, no device-side flags): `begin(c)` selects buffer c & 1 and points the engine at it; after the launch
+    `complete()` waits for this rank's launch (an event), for this rank's consumer of the OTHER buffer's previous content (its
+    release event), and then joins a barrier of the group.  Past the barrier every rank's rows of chunk c have landed in every
+    buffer, and every rank's consumer is done with what chunk c + 1 will overwrite.  The barrier costs a host round trip per
+    chunk (~0.1 ms) against milliseconds of link time per chunk.
+
+    How long a block stays: a rank's buffers are written by its PEERS, which may be one launch ahead of it.  The block `complete()`
+    returns is whole and stays until this rank's NEXT `complete()` call; a reader that needs it longer reads it under `reading(buf)`
+    (that next `complete()` then waits for the reader before it joins the barrier that lets the peers overwrite the buffer).  Unlike
+    ObsExchange's receive buffers, the block BEFORE the last one may already be receiving the peers' next chunk.
+
+    The receive buffers are handed out rank-major like ObsExchange's ([world, rows, n, obs_dim], here a strided VIEW of the
+    step-major storage; `step_major[b]` is the storage itself, the shape a vectorised consumer wants)."""
+
+    def __init__(self, engine, world, rank, rows, n, obs_dim, group=None):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib as L
+
+        if obs_dim != 4:
+            raise NotImplementedError("peer writes are built for the 4-float observation rows of the CartPole family")
+        if world > L.MAX_OBS_PEERS:
+            raise ValueError(f"world={world} > {L.MAX_OBS_PEERS} gathered buffers per launch")
+        self.engine, self.world, self.rank, self.rows, self.n, self.group = engine, world, rank, rows, n, group
+        self.device = engine.device
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.cuda = True
+        self._L = L
+        nbytes = rows * world * n * obs_dim * 4
+        self._own, handles = [], []
+        for _ in range(2):
+            ptr, h = C.c_void_p(), (C.c_ubyte * 64)()
+            L.check(L.lib().emei_peer_buffer_create(self.dev_index, nbytes, C.byref(ptr), h))
+            self._own.append(ptr.value)
+            handles.append(bytes(h))
+        self.distributed = world > 1 and dist.is_available() and dist.is_initialized()
+        if world > 1 and not self.distributed:
+            raise RuntimeError("PeerWriteExchange with world > 1 needs an initialised torch.distributed group (handles and barriers travel over it)")
+        self._opened = []
+        ptrs = [[None] * world, [None] * world]
+        if self.distributed:
+            all_handles = [None] * world
+            dist.all_gather_object(all_handles, handles, group=group)
+            for r in range(world):
+                for b in range(2):
+                    if r == rank:
+                        ptrs[b][r] = self._own[b]
+                    else:
+                        p = C.c_void_p()
+                        hb = (C.c_ubyte * 64).from_buffer_copy(all_handles[r][b])
+                        L.check(L.lib().emei_peer_buffer_open(self.dev_index, hb, C.byref(p)))
+                        self._opened.append(p.value)
+                        ptrs[b][r] = p.value
+        else:
+            ptrs = [[self._own[0]], [self._own[1]]]
+        self._ptrs = ptrs
+        with torch.cuda.device(self.device):
+            self.step_major = [torch.as_tensor(_DeviceArray(self._own[b], (rows, world * n, obs_dim)), device=self.device) for b in range(2)]
+        assert all(t.data_ptr() == self._own[b] for b, t in enumerate(self.step_major)), "torch copied the buffer instead of viewing it"
+        for t in self.step_major:
+            t.zero_()
+        torch.cuda.synchronize(self.device)
+        self.gathered = [t.view(rows, world, n, obs_dim).permute(1, 0, 2, 3) for t in self.step_major]
+        self._released = [None, None]
+        self._launched = None
+        self._current = None
+        self.collectives = 0  # exchanges completed (no collective runs; the name is ObsExchange's)
+        if self.distributed:
+            dist.barrier(group=group)  # every rank has mapped every buffer before anyone writes
+
+    # ObsExchange's surface, so that ShardedRollout and its consumers treat both alike
+    def fence(self, slot):
+        pass
+
+    def wait_all(self):
+        pass
+
+    def begin(self, chunk_index):
+        """Before the rollout launch of a chunk: the launch will write buffer `chunk_index & 1` of every rank."""
+        b = self.collectives & 1
+        self._current = b
+        self.engine.set_obs_peers(self._ptrs[b], self.world * self.n, self.rank * self.n)
+        return b
+
+    def complete(self):
+        """After the launch: returns the receive buffer once EVERY rank's rows are in it (see the class comment)."""
+        import torch.distributed as dist
+
+        b = self._current
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ev.synchronize()
+        other = self._released[b ^ 1]
+        if other is not None:  # this rank's consumer of the buffer the NEXT chunk overwrites
+            other.synchronize()
+            self._released[b ^ 1] = None
+        if self.distributed:
+            dist.barrier(group=self.group)
+        self.collectives += 1
+        self._current = None
+        return self.gathered[b]
+
+    def _index(self, buf):
+        for b in (0, 1):
+            if buf is self.gathered[b] or buf is self.step_major[b]:
+                return b
+        raise ValueError("not a receive buffer of this exchange")
+
+    def acquire(self, buf):
+        self._index(buf)  # complete() returned it: already whole
+        return buf
+
+    def release(self, buf):
+        b = self._index(buf)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._released[b] = ev
+
+    def reading(self, buf):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.acquire(buf)
+            try:
+                yield buf
+            finally:
+                self.release(buf)
+
+        return cm()
+
+    def last(self, back=0):
+        return self.gathered[(self.collectives - 1 - back) & 1]
+
+    def close(self):
+        """Unmap the peers' buffers, then (after a barrier: nobody writes or maps them any more) free this rank's own."""
+        import torch.distributed as dist
+
+        if self._own is None:
+            return
+        torch.cuda.synchronize(self.device)
+        try:
+            self.engine.set_obs_peers([], 0, 0)
+        except Exception:
+            pass  # the engine may already be closed
+        for ev in self._released:
+            if ev is not None:
+                ev.synchronize()
+        lib = self._L.lib()
+        for p in self._opened:
+            self._L.check(lib.emei_peer_buffer_close(self.dev_index, p))
+        self._opened = []
+        if self.distributed:
+            dist.barrier(group=self.group)
+        self.gathered = self.step_major = None
+        for p in self._own:
+            self._L.check(lib.emei_peer_buffer_destroy(self.dev_index, p))
+        self._own = None
+
+
 def synthetic_init_state(env, n_global, lo, hi, seed=0):
     """Initial states of SURVEY.md 8d: the reference's reset distribution drawn on the host for the
     GLOBAL env array (row-major like np_random.uniform(size=(B,4)), cartpole.py:153-156), then sliced."""
@@ -232,7 +409,12 @@ class ShardedRollout:
             raise ValueError(f"chunk {self.chunk} must divide the horizon {self.horizon}")
         self.n_chunks = self.horizon // self.chunk
         self.exchanging = world > 1 or bool(force_exchange)
+        if exchange_algo not in EXCHANGES:
+            raise ValueError(f"exchange_algo={exchange_algo!r}; known: {EXCHANGES}")
         self.exchange_algo = exchange_algo
+        self.peer_write = self.exchanging and exchange_algo == "peer_write"
+        if self.peer_write and gather != "per_chunk":
+            raise ValueError("exchange_algo='peer_write' returns every step's observation: gather='per_chunk' (chunks of at least 16 steps)")
         if init_noise is None:
             init_noise = 0.1 if env == "HalfCheetahRunning" else 5e-3
         self.engine = Engine(env, self.n, freq_rate=freq_rate, real_time_scale=real_time_scale, precision=precision,
@@ -286,7 +468,10 @@ class ShardedRollout:
             # a chunk's observation block is gathered straight from the rollout's output slice (slot = chunk index);
             # "final" copies the last row to a one-row staging buffer first (slot 0)
             rows = 1 if self.gather == "final" else K
-            self.xchg = ObsExchange(self.world, rows, self.n, self.obs_dim, self.n_chunks, self.device, algo=self.exchange_algo)
+            if self.peer_write:
+                self.xchg = PeerWriteExchange(self.engine, self.world, self.rank, rows, self.n, self.obs_dim)
+            else:
+                self.xchg = ObsExchange(self.world, rows, self.n, self.obs_dim, self.n_chunks, self.device, algo=self.exchange_algo)
             self.gathered = self.xchg.gathered
             self._stage = torch.empty((1, self.n, self.obs_dim), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize()
@@ -305,9 +490,15 @@ class ShardedRollout:
         for c in range(self.n_chunks):
             if self.exchanging:
                 self.xchg.fence(c)  # the gather that read this slice during the previous pass is over before it is rewritten
+            if self.peer_write:
+                self.xchg.begin(c)  # the launch below writes its observation rows into every rank's current buffer
             obs, rew, done = self.engine.rollout(self._act_chunks[c], auto_reset=True, out=self._out_chunks[c])
             last = obs
-            if self.exchanging and self.gather != "final":
+            if self.peer_write:
+                last = self.xchg.complete()
+                if on_gathered is not None:
+                    on_gathered(c, last)
+            elif self.exchanging and self.gather != "final":
                 last = self.xchg.exchange(c, obs)
                 if on_gathered is not None:
                     on_gathered(c, last)
@@ -320,6 +511,13 @@ class ShardedRollout:
             if on_gathered is not None:
                 on_gathered(0, last)
         return last
+
+    def close(self):
+        """Release the exchange's device memory (peer-mapped buffers need an orderly teardown on every rank) and the engine."""
+        if self.peer_write and self.xchg is not None:
+            self.xchg.close()
+        self.xchg = None
+        self.engine.close()
 
     def wait_gathers(self):
         """Make the launch stream wait for every outstanding observation all-gather."""
@@ -334,6 +532,8 @@ class ShardedRollout:
     def timed_launches_ms(self, k):
         """Mean duration of one rollout launch: k passes of back-to-back launches (no collective) bracketed by ONE
         pair of HIP events on the launch stream (no per-launch marker packets inside the timed span)."""
+        if self.peer_write:
+            self.engine.set_obs_peers([], 0, 0)  # the kernel alone: no peer stores (begin() points the engine at them again)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(k):
@@ -348,6 +548,8 @@ class ShardedRollout:
         import time
 
         out = self.engine.alloc_outputs(None)
+        if self.peer_write:
+            self.engine.set_obs_peers([], 0, 0)
         for t in range(10):
             self.engine.step(self.actions[t % self.horizon], auto_reset=True, out=out)
         torch.cuda.synchronize()

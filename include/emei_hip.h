@@ -30,8 +30,10 @@ extern "C" {
  * 5: emei_step_host (page-locked host values in and out; for n_envs == 1 of the 4-state family one launch whose last store is a
  *    completion word the library polls).
  * 6: emei_config.ode_method (classic control's ODE_approximation(method="rk4"), opt-in) and emei_config.rollout_chunk_steps
- *    (struct_size 408; a 400-byte caller gets euler / automatic), emei_get_rollout_faults, EMEI_NEXT_OBS_ODE_RK4. */
-#define EMEI_ABI_VERSION 6
+ *    (struct_size 408; a 400-byte caller gets euler / automatic), emei_get_rollout_faults, EMEI_NEXT_OBS_ODE_RK4.
+ * 7: emei_set_obs_peers + emei_peer_buffer_create / open / close / destroy (multi-GPU observation return by peer writes from the
+ *    rollout kernel), EMEI_KERNEL_PEND_STAGED_PEERS_FREQ1 / EMEI_KERNEL_PEND_STAGED_PEERS. */
+#define EMEI_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define EMEI_API __attribute__((visibility("default")))
@@ -294,9 +296,40 @@ enum emei_kernel_id {
     EMEI_KERNEL_BODY = 5,              /* body_rollout_kernel<Body, false> (euler / semi-implicit euler) */
     EMEI_KERNEL_BODY_RK4 = 6,          /* body_rollout_kernel<Body, true> */
     EMEI_KERNEL_BODY_CHUNKED = 7,      /* body_rollout_kernel<Body, false> as (64 envs) x (chunk of steps) work items (rollout_chunk_steps) */
-    EMEI_KERNEL_BODY_RK4_CHUNKED = 8   /* body_rollout_kernel<Body, true> likewise */
+    EMEI_KERNEL_BODY_RK4_CHUNKED = 8,  /* body_rollout_kernel<Body, true> likewise */
+    EMEI_KERNEL_PEND_STAGED_PEERS_FREQ1 = 9, /* pend_rollout_staged_peers_kernel<Env, ActT, true>: with the peer stores of emei_set_obs_peers */
+    EMEI_KERNEL_PEND_STAGED_PEERS = 10       /* pend_rollout_staged_peers_kernel<Env, ActT, false> */
 };
 EMEI_API int emei_last_rollout_kernel(emei_env* h);
+
+/* --- Multi-GPU observation return by PEER WRITES (one process per GPU; north_star: "shards env instances across up to 8 GPUs of one node
+ * ... only for the batched observation return"; SURVEY §5: "hipIpc peer writes from the step kernel's epilogue").  The reference has no
+ * counterpart (it is a single-process CPU library: zoo/util.py:54-73 steps one env); this replaces the RCCL all-gather that follows a
+ * rollout launch: the rollout kernel itself stores every step's observation row into the gathered buffer of every rank, so the block is
+ * neither re-read from HBM nor moved by a separate collective.
+ *
+ * emei_set_obs_peers: from now on emei_rollout (emei_step likewise: it is a rollout of one step, hence refused) ALSO stores the observation of step t, env i at
+ *     ((float*)peer_obs[p])[((int64_t)t * row_envs + col_offset + i) * obs_dim + k],  k < obs_dim,  for every p < n_peers
+ * i.e. each peer buffer is a gathered block [n_steps, row_envs, obs_dim] float32 and this handle's envs are its columns
+ * [col_offset, col_offset + n_envs).  peer_obs[p] are device pointers valid on this handle's device: memory of this process, or of another
+ * rank mapped with emei_peer_buffer_open (16-byte aligned; row_envs >= col_offset + n_envs; the caller sizes them for the longest
+ * rollout it will launch).  n_peers = 0 switches it off; at most EMEI_MAX_OBS_PEERS (a rank's own gathered buffer counts as one).
+ * Built for the staged kernel of the CartPole family (BASELINE configs[4]'s env; n_envs a multiple of 64, n_steps >= 16, 16-byte
+ * aligned buffers): any other rollout with peers set FAILS with EMEI_ERR_UNSUPPORTED — nothing is skipped silently.
+ * Ordering is the caller's: a peer may read a block once the writer's launch has completed (stream / event synchronisation on the
+ * writer, then any host-side barrier between the ranks), and the writer may reuse a buffer once its readers are done. */
+#define EMEI_MAX_OBS_PEERS 8
+EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset);
+
+/* Device memory another process of this node can map: hipMalloc + hipIpcGetMemHandle / hipIpcOpenMemHandle (the handle is 64 opaque
+ * bytes to be carried to the other rank by whatever the host side has: torch.distributed.all_gather_object, MPI, a pipe).  `device` is
+ * the HIP device ordinal of the CALLER (the creator allocates there; the opener maps the creator's memory into that device's address
+ * space, peer access over xGMI).  A buffer is closed by every opener before its creator destroys it. */
+typedef struct emei_ipc_handle { unsigned char bytes[64]; } emei_ipc_handle;
+EMEI_API int emei_peer_buffer_create(int device, uint64_t bytes, void** dev_ptr_out, emei_ipc_handle* handle_out);
+EMEI_API int emei_peer_buffer_open(int device, const emei_ipc_handle* handle, void** dev_ptr_out);
+EMEI_API int emei_peer_buffer_close(int device, void* dev_ptr);
+EMEI_API int emei_peer_buffer_destroy(int device, void* dev_ptr);
 
 /* Sorted indices of the envs whose last step reported done (wavefront-ballot compaction of the done
  * masks the step kernels leave behind): idx_out [n_envs] int32 (first *count_out entries valid),

@@ -67,8 +67,17 @@ def main():
                     seen.append((p, c, buf.clone(), float(x[0, 0].item() * 0)))
         return on_gathered
 
+    def quick_consumer(p):  # peer_write without --slow-consumer: every chunk's buffer is still copied out under reading()
+        def on_gathered(c, buf):
+            with torch.cuda.stream(consumer_stream):
+                with sr.xchg.reading(buf):
+                    seen.append((p, c, buf.clone(), 0.0))
+        return on_gathered
+
+    pw = a.exchange == "peer_write"
+    copy_all = a.slow_consumer or pw
     for p in range(a.passes):
-        last = sr.run_pass(on_gathered=slow_consumer(p) if a.slow_consumer else None)
+        last = sr.run_pass(on_gathered=slow_consumer(p) if a.slow_consumer else (quick_consumer(p) if pw else None))
         sr.wait_gathers()
         torch.cuda.synchronize()
         want = [e.rollout(acts, auto_reset=True)[0] for e, acts in refs]  # [T, n, 4] per rank
@@ -78,24 +87,32 @@ def main():
         assert tuple(last.shape) == (world, rows, n, 4), tuple(last.shape)
         # the two receive buffers hold the LAST TWO collectives of the pass
         n_coll = 1 if a.gather == "final" else sr.n_chunks
-        for back in range(min(2, n_coll)):
+        # (peer writes: a rank's buffers are written by its PEERS, who may be a launch ahead — the block before the last is only
+        # guaranteed while its reader holds it (reading()); the copies taken under reading() are checked below instead)
+        for back in range(min(1 if pw else 2, n_coll)):
             buf = sr.xchg.last(back)
             c = n_coll - 1 - back
             for r in range(world):
                 blk = want[r][-1:] if a.gather == "final" else want[r][c * K:(c + 1) * K]
                 assert torch.equal(buf[r], blk), f"pass {p}: collective {c}, block of rank {r}"
-        if a.slow_consumer:  # every buffer the consumer copied out holds the block of ITS collective, of every rank
+        if copy_all:  # every buffer the consumer copied out holds the block of ITS collective, of every rank
             consumer_stream.synchronize()
             for pp, c, copy, _ in [s for s in seen if s[0] == p]:
                 for r in range(world):
                     blk = want[r][-1:] if a.gather == "final" else want[r][c * K:(c + 1) * K]
                     assert torch.equal(copy[r], blk), f"slow consumer, pass {pp}: collective {c}, block of rank {r} was overwritten"
-    if a.slow_consumer:
+    if copy_all:
         assert len(seen) == a.passes * (1 if a.gather == "final" else sr.n_chunks)
     assert sr.collectives == a.passes * (1 if a.gather == "final" else sr.n_chunks)
+    if a.exchange == "peer_write":  # the step-major storage is the same data in global env order
+        sm = sr.xchg.step_major[(sr.collectives - 1) & 1]
+        assert torch.equal(sm, torch.cat([w[-K:] for w in want], dim=1)), "step-major view"
+        assert "peers" in sr.kernel_name
     dist.barrier()
+    n_coll, kernel = sr.collectives, sr.kernel_name
+    sr.close()  # peer-mapped buffers: unmapped by everybody before their owners free them
     if rank == 0:
-        print(f"SHARDED_OK world={world} backend={a.backend} gather={a.gather} chunk={K} collectives={sr.collectives} kernel={sr.kernel_name}", flush=True)
+        print(f"SHARDED_OK world={world} backend={a.backend} gather={a.gather} chunk={K} collectives={n_coll} kernel={kernel}", flush=True)
     dist.destroy_process_group()
 
 

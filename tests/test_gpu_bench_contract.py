@@ -130,6 +130,21 @@ def test_collective_is_the_other_exchange_when_direct_is_the_runs_own():
     assert "value_direct_exchange" not in j
 
 
+def test_peer_write_exchange_as_the_runs_own_form():
+    """--exchange peer_write (opt-in): the rollout kernel writes the observation return into every rank's hipIpc-mapped buffer; the
+    line says so, the collective is timed beside it, the launch that ran is the peers kernel's plain twin for the kernel-only timing."""
+    e = dict(os.environ, EMEI_BENCH_SHARE_GPU="1", EMEI_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--exchange", "peer_write",
+                        "--envs-per-gpu", "16384"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["exchange"] == "peer_write" and "WITHOUT a collective" in j["config"]["obs_allgather"]
+    assert j["value"] > 0 and j["value_collective_exchange"]["exchange"] == "collective" and "extras_error" not in j
+    assert j["compute_only"]["value"] > j["value"]
+
+
 @pytest.mark.parametrize("how", ["hang", "raise"])
 def test_a_hang_or_an_error_after_the_timed_region_does_not_cost_the_line(how):
     """The measurements that follow the timed region at N > 1 (compute_only, value_final_gather, the other exchange form) run under a

@@ -54,3 +54,14 @@ def test_slow_consumer_never_sees_an_overwritten_buffer(backend, nproc):
     out = _run(nproc, 29615 + nproc, "--backend", backend, "--gather", "per_chunk", "--chunk", "8", "--horizon", "64", "--slow-consumer",
                *(("--envs", "65536") if backend == "nccl" else ()))
     assert f"world={nproc}" in out
+
+
+@pytest.mark.parametrize("nproc,extra", [(2, ()), (3, ()), (2, ("--slow-consumer",))])
+def test_peer_write_exchange(nproc, extra):
+    """The observation return by peer writes from the rollout kernel (sharding.PeerWriteExchange; emei_set_obs_peers +
+    emei_peer_buffer_*): 2 and 3 processes sharing the one GPU map each other's gathered buffers through hipIpc, every rank's kernel
+    stores its rows into every rank's buffer, and every block of every rank is checked against a local recomputation — no collective
+    moves an observation (gloo carries the 64-byte handles and the barriers)."""
+    out = _run(nproc, 29620 + nproc + len(extra), "--backend", "gloo", "--gather", "per_chunk", "--chunk", "16", "--horizon", "64",
+               "--exchange", "peer_write", *extra)
+    assert f"world={nproc}" in out and "peers" in out
