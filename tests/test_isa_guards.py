@@ -64,9 +64,11 @@ def functions(tmp_path_factory):
 
 
 def _staged(functions):
-    fs = {k: v for k, v in functions.items() if "pend_rollout_staged_kernel" in k}
-    # CartPole x {u8, i32, i64} x {FREQ1, loop} x 2 variants x 2 precisions + InvPend x f32 x 2 x 4 x 2
-    assert len(fs) >= 24 + 16, sorted(fs)
+    fs = {k: v for k, v in functions.items() if "pend_rollout_staged_kernel" in k or "pend_rollout_staged_peers_kernel" in k}
+    # CartPole x {u8, i32, i64} x {FREQ1, loop} x 2 variants x 2 precisions + InvPend x f32 x 2 x 4 x 2, + the CartPole kernels
+    # once more with the peer stores of emei_set_obs_peers (the same tile pipeline, more stores behind the loads)
+    assert len(fs) >= 24 + 16 + 24, sorted(fs)
+    assert sum("staged_peers_kernel" in k for k in fs) >= 24
     return fs
 
 

@@ -41,6 +41,13 @@ while time.time() - t0 < budget:
     engs = [Engine(name, n, rollout_chunk_steps=c, **kw) for c in (-1, chunk_b, 0)]
     for e in engs:
         e.reset(kw["seed"])
+    # round 5: the CartPole family's second engine also writes its observation rows into a random number of gathered buffers
+    # (emei_set_obs_peers) when the staged kernel serves the shape: same bits, and the rows land at their columns
+    peers = None
+    if classic and n % 64 == 0 and T >= 16 and rng.integers(2):
+        col, total = int(rng.integers(0, 3)) * n, 3 * n
+        peers = [torch.full((T, total, 4), float("nan"), device="cuda") for _ in range(int(rng.integers(1, 9)))]
+        engs[1].set_obs_peers(peers, total, col)
     if engs[0].act_dim == 0:
         acts = torch.randint(0, 2, (T, n), device="cuda", dtype=[torch.uint8, torch.int32, torch.int64][rng.integers(3)])
     else:
@@ -48,6 +55,11 @@ while time.time() - t0 < budget:
         acts = (torch.rand(shape, device="cuda") * 2.4 - 1.2).float()
     ref = engs[0].rollout(acts, auto_reset=True)
     again = engs[1].rollout(acts, auto_reset=True)
+    if peers is not None:
+        for pb in peers:
+            assert bool((pb[:, col:col + n] == ref[0]).all()), ("peer rows", name, n, T, kw)
+            assert bool(pb[:, :col].isnan().all()) and bool(pb[:, col + n:].isnan().all()), ("peer columns", name, n, T, kw)
+        engs[1].set_obs_peers([], 0, 0)
     cuts = sorted(set([0, T] + [int(c) for c in rng.integers(0, T + 1, 2)]))
     parts = [engs[2].rollout(acts[a:b].contiguous(), auto_reset=True) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
     for k in range(3):
