@@ -279,6 +279,9 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
     unsigned long long spare_mask = 0ull;
     uint32_t spare_flag = 0u;
     auto maybe_reset = [&]() __attribute__((always_inline)) {
+#if defined(EMEI_NO_RESET)  // experiment (timing only, wrong results after the first done): what the per-step reset check and its block boundary cost
+        return;
+#endif
         EMEI_STAT_WAVE(16);  // staged-kernel event counters of a -DEMEI_NEWTON_STATS build (tools/pend_stats.py): env-steps (waves)
         const unsigned long long done_mask = __ballot(done != 0) & reset_mask;
         // cold for most envs: laid out of line so that the usual case falls through (Env::kResetLikely: in line)
