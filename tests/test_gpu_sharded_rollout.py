@@ -62,6 +62,6 @@ def test_peer_write_exchange(nproc, extra):
     emei_peer_buffer_*): 2 and 3 processes sharing the one GPU map each other's gathered buffers through hipIpc, every rank's kernel
     stores its rows into every rank's buffer, and every block of every rank is checked against a local recomputation — no collective
     moves an observation (gloo carries the 64-byte handles and the barriers)."""
-    out = _run(nproc, 29620 + nproc + len(extra), "--backend", "gloo", "--gather", "per_chunk", "--chunk", "16", "--horizon", "64",
+    out = _run(nproc, 29620 + 2 * nproc + len(extra), "--backend", "gloo", "--gather", "per_chunk", "--chunk", "16", "--horizon", "64",
                "--exchange", "peer_write", *extra)
     assert f"world={nproc}" in out and "peers" in out
