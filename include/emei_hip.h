@@ -5,7 +5,8 @@
  * class surface.  Each entry point below names the reference interface it replaces (file:line under
  * /root/reference).  All pointers are caller-owned DEVICE-ACCESSIBLE pointers (device memory, e.g.
  * torch.Tensor.data_ptr(), or pinned host memory mapped into the device address space), contiguous,
- * never retained past the call.  The library never allocates outputs, never
+ * never retained past the call (one exception: the gathered buffers handed to emei_set_obs_peers stay registered, and are written by
+ * every following rollout, until the list is replaced or cleared).  The library never allocates outputs, never
  * synchronises the stream and never throws across the boundary.  `stream` is a hipStream_t passed
  * as void* (NULL = the default stream).  One handle <-> one device: calls on a handle must be made with
  * that device current (checked: EMEI_ERR_INVALID otherwise; emei_create itself restores the caller's
