@@ -104,7 +104,7 @@ SYMBOLS = {
     "emei_get_solver_cap_hits": (C.c_int, [_vp, _vp, _vp]),
     "emei_get_rollout_faults": (C.c_int, [_vp, _vp, _vp]),
     "emei_last_rollout_kernel": (C.c_int, [_vp]),
-    "emei_set_obs_peers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _i64, _i64]),
+    "emei_set_obs_peers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _i64, _i64, _i32]),
     "emei_peer_buffer_create": (C.c_int, [C.c_int, _u64, C.POINTER(_vp), _vp]),
     "emei_peer_buffer_open": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "emei_peer_buffer_close": (C.c_int, [C.c_int, _vp]),

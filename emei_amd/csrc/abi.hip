@@ -500,7 +500,7 @@ extern "C" EMEI_API int emei_get_rollout_faults(emei_env* h, uint64_t* count_out
     return EMEI_OK;
 }
 
-extern "C" EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset) {
+extern "C" EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset, int32_t max_steps) {
     if (!h) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: null handle");
     if (n_peers == 0) {
         h->peers = ObsPeers();
@@ -508,6 +508,7 @@ extern "C" EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const
     }
     if (n_peers < 0 || n_peers > EMEI_MAX_OBS_PEERS) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: n_peers=%d outside 0..%d", n_peers, EMEI_MAX_OBS_PEERS);
     if (!peer_obs) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: null pointer list");
+    if (max_steps < 1) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: max_steps=%d < 1", max_steps);
     if (col_offset < 0 || row_envs < col_offset + h->cfg.n_envs)
         return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: columns [%lld, %lld) do not fit a row of %lld envs", (long long)col_offset,
                     (long long)(col_offset + h->cfg.n_envs), (long long)row_envs);
@@ -518,7 +519,7 @@ extern "C" EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const
         if (!peer_obs[p] || ((uintptr_t)peer_obs[p] & 15u)) return fail(EMEI_ERR_INVALID, "emei_set_obs_peers: peer %d is null or not 16-byte aligned", p);
         P.obs[p] = peer_obs[p];
     }
-    P.row_envs = row_envs, P.col = col_offset, P.count = n_peers;
+    P.row_envs = row_envs, P.col = col_offset, P.count = n_peers, P.max_steps = max_steps;
     h->peers = P;
     return EMEI_OK;
 }
@@ -602,6 +603,9 @@ extern "C" EMEI_API int emei_rollout(emei_env* h, int32_t n_steps, const void* a
     if (flags & ~EMEI_FLAG_AUTO_RESET) return fail(EMEI_ERR_INVALID, "emei_rollout: unknown flags 0x%x", flags);
     if (check_action_dtype(h, action_dtype) != EMEI_OK) return EMEI_ERR_INVALID;
     int rc;
+    if (h->peers.count > 0 && n_steps > h->peers.max_steps)
+        return fail(EMEI_ERR_INVALID, "emei_rollout: n_steps=%d but the registered observation peers hold %d rows (emei_set_obs_peers)", n_steps,
+                    h->peers.max_steps);
     if (!steps_as_body(h->cfg)) {
         PendLaunch L = pend_base(h, stream);
         L.op = PEND_OP_ROLLOUT;

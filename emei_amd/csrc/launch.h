@@ -14,6 +14,7 @@ struct ObsPeers {
     void* obs[EMEI_MAX_OBS_PEERS] = {};
     int64_t row_envs = 0, col = 0;
     int count = 0;
+    int32_t max_steps = 0;  // rows of every buffer
 };
 
 struct PendLaunch {

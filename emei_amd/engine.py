@@ -155,15 +155,23 @@ class Engine:
         L.check(L.lib().emei_get_rollout_faults(self._h, _ptr(out), _stream()))
         return int(out.item())
 
-    def set_obs_peers(self, peers, row_envs, col_offset):
+    def set_obs_peers(self, peers, row_envs, col_offset, max_steps=None):
         """emei_set_obs_peers: from now on every rollout ALSO stores each step's observation row into the gathered buffers `peers`
         (device pointers as ints, or float32 tensors [rows, row_envs, obs_dim]; at most _lib.MAX_OBS_PEERS), this engine's envs at
         columns [col_offset, col_offset + n_envs) — the multi-GPU observation return by peer writes (sharding.PeerWriteExchange).
-        An empty list switches it off.  Rollouts the staged CartPole kernel cannot serve then raise instead of skipping the peers."""
+        An empty list switches it off.  Rollouts the staged CartPole kernel cannot serve then raise instead of skipping the peers.
+        max_steps: rows of every buffer (taken from the tensors when they are tensors): a longer rollout is refused."""
         self._live()
         ptrs = [int(p.data_ptr()) if torch.is_tensor(p) else int(p) for p in peers]
+        if max_steps is None and ptrs:
+            if not all(torch.is_tensor(p) for p in peers):
+                raise ValueError("set_obs_peers: max_steps is needed with raw pointers")
+            for p in peers:
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.dim() != 3 or p.shape[1] != row_envs or p.shape[2] != self.obs_dim:
+                    raise ValueError(f"set_obs_peers: a peer buffer is float32 [rows, {row_envs}, {self.obs_dim}], contiguous; got {p.dtype} {tuple(p.shape)}")
+            max_steps = min(int(p.shape[0]) for p in peers)
         arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
-        L.check(L.lib().emei_set_obs_peers(self._h, len(ptrs), arr, int(row_envs), int(col_offset)))
+        L.check(L.lib().emei_set_obs_peers(self._h, len(ptrs), arr, int(row_envs), int(col_offset), int(max_steps or 0)))
         self._peer_refs = [p for p in peers if torch.is_tensor(p)]  # keep local targets alive while they are written to
 
     def last_kernel(self):

@@ -272,7 +272,7 @@ class PeerWriteExchange:
         """Before the rollout launch of a chunk: the launch will write buffer `chunk_index & 1` of every rank."""
         b = self.collectives & 1
         self._current = b
-        self.engine.set_obs_peers(self._ptrs[b], self.world * self.n, self.rank * self.n)
+        self.engine.set_obs_peers(self._ptrs[b], self.world * self.n, self.rank * self.n, max_steps=self.rows)
         return b
 
     def complete(self):

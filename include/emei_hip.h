@@ -313,14 +313,14 @@ EMEI_API int emei_last_rollout_kernel(emei_env* h);
  *     ((float*)peer_obs[p])[((int64_t)t * row_envs + col_offset + i) * obs_dim + k],  k < obs_dim,  for every p < n_peers
  * i.e. each peer buffer is a gathered block [n_steps, row_envs, obs_dim] float32 and this handle's envs are its columns
  * [col_offset, col_offset + n_envs).  peer_obs[p] are device pointers valid on this handle's device: memory of this process, or of another
- * rank mapped with emei_peer_buffer_open (16-byte aligned; row_envs >= col_offset + n_envs; the caller sizes them for the longest
- * rollout it will launch).  n_peers = 0 switches it off; at most EMEI_MAX_OBS_PEERS (a rank's own gathered buffer counts as one).
+ * rank mapped with emei_peer_buffer_open (16-byte aligned; row_envs >= col_offset + n_envs; each holds max_steps rows: a rollout of
+ * more steps is refused with EMEI_ERR_INVALID instead of writing past them).  n_peers = 0 switches it off; at most EMEI_MAX_OBS_PEERS (a rank's own gathered buffer counts as one).
  * Built for the staged kernel of the CartPole family (BASELINE configs[4]'s env; n_envs a multiple of 64, n_steps >= 16, 16-byte
  * aligned buffers): any other rollout with peers set FAILS with EMEI_ERR_UNSUPPORTED — nothing is skipped silently.
  * Ordering is the caller's: a peer may read a block once the writer's launch has completed (stream / event synchronisation on the
  * writer, then any host-side barrier between the ranks), and the writer may reuse a buffer once its readers are done. */
 #define EMEI_MAX_OBS_PEERS 8
-EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset);
+EMEI_API int emei_set_obs_peers(emei_env* h, int n_peers, void* const* peer_obs, int64_t row_envs, int64_t col_offset, int32_t max_steps);
 
 /* Device memory another process of this node can map: hipMalloc + hipIpcGetMemHandle / hipIpcOpenMemHandle (the handle is 64 opaque
  * bytes to be carried to the other rank by whatever the host side has: torch.distributed.all_gather_object, MPI, a pipe).  `device` is

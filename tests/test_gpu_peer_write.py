@@ -65,7 +65,14 @@ def test_eight_peers_and_the_limits():
     with pytest.raises(ValueError, match="do not fit"):
         e.set_obs_peers(peers[:1], n, 64)
     with pytest.raises(ValueError, match="aligned"):
-        e.set_obs_peers([peers[0].data_ptr() + 4], n, 0)
+        e.set_obs_peers([peers[0].data_ptr() + 4], n, 0, max_steps=T)
+    with pytest.raises(ValueError, match="max_steps"):
+        e.set_obs_peers([peers[0].data_ptr()], n, 0)
+    with pytest.raises(ValueError, match="float32"):
+        e.set_obs_peers([torch.zeros((T, n, 4), device=e.device, dtype=torch.float64)], n, 0)
+    e.set_obs_peers(peers[:2], n, 0)
+    with pytest.raises(ValueError, match="hold 16 rows"):  # a longer rollout would write past the buffers: refused, nothing launched
+        e.rollout(torch.randint(0, 2, (T + 16, n), device=e.device, dtype=torch.uint8))
 
 
 def test_paths_without_peer_stores_refuse_instead_of_skipping():
