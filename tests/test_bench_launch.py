@@ -104,3 +104,33 @@ def test_host_cpu_share_is_capped_by_the_cgroup_quota(monkeypatch):
     assert bench.host_cpu_share() == 256
     monkeypatch.setattr(builtins, "open", fake("150000 100000\n"))  # 1.5 CPUs -> 2 threads
     assert bench.host_cpu_share() == 2
+
+
+def test_extras_guard_prints_the_line_and_leaves_when_the_deadline_passes(tmp_path):
+    """bench.ExtrasGuard (N > 1: the measurements after the timed region run under a deadline): a main thread that never comes back
+    from an "extra" still yields rank 0's line, marked, and exit status 0; other ranks leave silently; a guard that is finished in
+    time lets the caller print, once."""
+    prog = tmp_path / "guard.py"
+    prog.write_text(
+        "import sys, time, json\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "rank, mode = int(sys.argv[1]), sys.argv[2]\n"
+        "out = {'value': 1.5, 'n_gpus': 2}\n"
+        "g = bench.ExtrasGuard(out, rank, 0.3).start()\n"
+        "if mode == 'hang':\n"
+        "    out['compute_only'] = 7\n"
+        "    time.sleep(60)\n"
+        "    print('NOT REACHED')\n"
+        "else:\n"
+        "    assert g.finish() and not g.finish()\n"
+        "    time.sleep(0.6)\n"
+        "    print(json.dumps(out))\n")
+    r0 = subprocess.run([sys.executable, str(prog), "0", "hang"], capture_output=True, text=True, timeout=60)
+    assert r0.returncode == 0 and "NOT REACHED" not in r0.stdout
+    line = __import__("json").loads(r0.stdout.strip())
+    assert line["value"] == 1.5 and line["compute_only"] == 7 and "extras_timed_out" in line
+    r1 = subprocess.run([sys.executable, str(prog), "1", "hang"], capture_output=True, text=True, timeout=60)
+    assert r1.returncode == 0 and r1.stdout.strip() == ""
+    ok = subprocess.run([sys.executable, str(prog), "0", "fine"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and "extras_timed_out" not in ok.stdout and ok.stdout.count("{") == 1
