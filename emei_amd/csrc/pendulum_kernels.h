@@ -326,11 +326,16 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
     // is then a scalar row base plus this constant: no 64-bit vector multiply on the hot path)
     const int64_t rew_lane_off = (int64_t)(lane >> 4) * n + i0 + ((lane & 15) << 2);  // 16 lanes x 16 B per row
     const int64_t done_lane_off = (int64_t)(lane >> 2) * n + i0 + ((lane & 3) << 4);  // 4 lanes x 16 B per row
+#if defined(EMEI_EXP_FLUSH_ROW0)  // experiment (timing only): the reward / done flushes always hit the first rows
+#define EMEI_FLUSH_ROW(r) ((r) & 0)
+#else
+#define EMEI_FLUSH_ROW(r) (r)
+#endif
     auto store_rew_rows = [&](int64_t row0, const float4& v) __attribute__((always_inline)) {
-        *(float4*)(a.reward_out + row0 * n + rew_lane_off) = v;
+        *(float4*)(a.reward_out + EMEI_FLUSH_ROW(row0) * n + rew_lane_off) = v;
     };
     auto store_done_rows = [&](int64_t row0, const uint4& v) __attribute__((always_inline)) {
-        if (kStage == 16 || lane < 4 * kStage) *(uint4*)(a.done_out + row0 * n + done_lane_off) = v;  // kStage rows x 64 B
+        if (kStage == 16 || lane < 4 * kStage) *(uint4*)(a.done_out + EMEI_FLUSH_ROW(row0) * n + done_lane_off) = v;  // kStage rows x 64 B
     };
 
     // Issue priority (Env::kRotatePriority: the InvertedPendulum kernels).  The SIMD's arbiter serves the OLDEST of its ready waves
@@ -394,7 +399,11 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
                 R o[4], rew;
                 advance(act_now, o, rew);
                 const float4 obs4 = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+#if defined(EMEI_EXP_OBS_ROW0)  // experiment (timing only): the observation stores alternate between rows 0 and 1 — the same instructions, no HBM write stream
+                (a.obs_out + (int64_t)((t0 + j) & 1) * n)[li] = obs4;
+#else
                 (a.obs_out + (int64_t)(t0 + j) * n)[li] = obs4;
+#endif
                 store_obs_peers(t0 + j, obs4);
                 if (q == 0) {  // rows staged during the previous group: their LDS read has landed
                     if (t0 + j > 0) store_rew_rows(t0 + j - 4, rew_pend);
