@@ -65,6 +65,7 @@ struct CartPole {
     static constexpr unsigned kSplitMaxRounds = EMEI_SPLIT_MAX_ROUNDS;
     static constexpr bool kXcdContiguous = true;  // pendulum_kernels.h: the env_block map of large shards
     static constexpr bool kPeerWrite = true;      // pendulum_kernels.h: pend_rollout_staged_peers_kernel is instantiated (emei_set_obs_peers)
+    static constexpr bool kTileBarrier = VARIANT == 0;  // pendulum_kernels.h: the block's waves meet once per tile (SwingUp; Balancing loses 4-5 %)
     // Balancing under random actions: the pole falls within ~20 steps, some lane of a wave resets in 95 % of its env-steps
     // (SwingUp: 20 %) — the reset block in line (pendulum_kernels.h:maybe_reset)
     static constexpr bool kResetLikely = VARIANT == 1;
@@ -418,6 +419,7 @@ struct InvPend {
     static constexpr unsigned kSplitMaxRounds = 0;
     static constexpr bool kXcdContiguous = EMEI_IP_XCD_CONTIGUOUS != 0;
     static constexpr bool kPeerWrite = false;  // emei_set_obs_peers: built for the CartPole family (configs[4]); UNSUPPORTED here
+    static constexpr bool kTileBarrier = false;  // measured: nothing (+-1 %)
     // config 3: some lane of a wave resets in 95 % of its env-steps (random pushes of +-300 N run the cart off the rail in
     // ~20 steps): the reset block is laid out in line, not behind two taken branches
     static constexpr bool kResetLikely = true;

@@ -168,6 +168,9 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 // steps per staged tile: 16 for one-byte actions (1 KiB of LDS per wave and buffer); 8 for 4- and 8-byte actions, so that
 // the double-buffered tiles of a 256-thread block stay at 16 / 32 KiB and four blocks (with the other slices) fit a CU's
 // 160 KiB: config 3 runs 4 waves per SIMD
+#ifndef EMEI_TILE_BARRIER
+#define EMEI_TILE_BARRIER 1  // 0: a variant build without the per-tile block barrier of the staged kernel (Env::kTileBarrier), for A/B runs
+#endif
 #ifndef EMEI_PRIO_ROTATE
 #define EMEI_PRIO_ROTATE 1  // 0: a variant build without the priority rotation of the staged kernel, for A/B runs
 #endif
@@ -429,6 +432,14 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
         // checks the emitted immediate and the stores of the loop body in the shipped code object.
         static_assert(kTileWaitKeep == kStage && kTileWaitKeep < 64, "one unconditional obs store per staged step");
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kTileWaitKeep) : "memory");
+        // Env::kTileBarrier (CartPoleSwingUp): the four waves of a block meet here, once per tile.  They work on 256 neighbouring envs — 4 KiB of
+        // every output row — and otherwise drift apart; kept within a tile of each other their pieces of a row reach the memory system
+        // together.  Same-box A/B on five boxes: 65 536 envs 0.287-0.294 -> 0.260-0.267 ms on the three slow ones, 0.260 -> 0.263 on a fast
+        // one (the barrier evens the boxes out at the fast ones' time); 131 072 envs -5..-9 %, 524 288 -4 %, 1 048 576 -6..-11 %.  Meeting every
+        // 4 steps is no better.  CartPoleBalancing resets every ~15 steps (a spare redraw is ~150 instructions for the whole wave): its
+        // waves wait for each other instead, +4-5 % — not applied; nothing for the InvertedPendulum kernels (four waves per SIMD).
+        // Waves of a partial last block that returned above do not take part (the hardware counts the waves still alive).
+        if constexpr (EMEI_TILE_BARRIER != 0 && Env::kTileBarrier) __builtin_amdgcn_s_barrier();
     }
     if (t0 > 0) {
         store_rew_rows(t0 - 4, rew_pend);
