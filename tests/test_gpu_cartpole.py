@@ -271,3 +271,23 @@ def test_step_launches_are_graph_capturable():
         r_obs, r_rew, r_done = b.rollout(acts, auto_reset=True)
         assert torch.equal(obs, r_obs) and torch.equal(rew, r_rew) and torch.equal(done, r_done)
     assert torch.equal(a.get_state(), b.get_state())
+
+
+@pytest.mark.parametrize("n", [64, 128, 192, 320])
+def test_partial_last_block_with_the_tile_barrier(n):
+    """The staged SwingUp kernel's waves meet at a workgroup barrier once per tile (Env::kTileBarrier); a shard of 1, 2, 3 or 5 waves leaves
+    the last 256-thread block partly empty — its absent waves return before the first barrier and must not be waited for.  Rollout ==
+    repeated step, bit for bit, and the staged kernel is what ran."""
+    from emei_amd import _lib
+    from emei_amd.engine import Engine
+
+    T = 48
+    a, b = Engine("CartPoleSwingUp", n, max_episode_steps=20, seed=2), Engine("CartPoleSwingUp", n, max_episode_steps=20, seed=2)
+    a.reset(2), b.reset(2)
+    acts = torch.randint(0, 2, (T, n), device=a.device, dtype=torch.uint8)
+    obs, rew, done = a.rollout(acts, auto_reset=True)
+    assert a.last_kernel() == _lib.KERNEL_PEND_STAGED_FREQ1
+    for t in range(T):
+        o, r, d = b.step(acts[t], auto_reset=True)
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t])
+    assert torch.equal(a.get_state(), b.get_state())
