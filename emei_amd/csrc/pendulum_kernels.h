@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 //   obs     : already 16 B per lane, stored directly
 // => 1.31 vector stores + 1/16 loads per env-step instead of 3 stores + 1 load, and no 64 B
 // partial-line byte stores.  LDS slices are wave-private (LDS operations of one wave execute in
-// order), so there is no barrier anywhere.
+// order), so no barrier is NEEDED anywhere; the one barrier of the SwingUp kernel (once per tile, Env::kTileBarrier) is there for the
+// memory system, not for correctness.
 // steps per staged tile: 16 for one-byte actions (1 KiB of LDS per wave and buffer); 8 for 4- and 8-byte actions, so that
 // the double-buffered tiles of a 256-thread block stay at 16 / 32 KiB and four blocks (with the other slices) fit a CU's
 // 160 KiB: config 3 runs 4 waves per SIMD
