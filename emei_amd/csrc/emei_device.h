@@ -171,6 +171,34 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 16-byte output stores of the staged rollout kernels with the NON-TEMPORAL hint (global_store_dwordx4 ... nt).  The rollout's
+// outputs are written once and read by nobody on this GPU during the launch; without the hint the reward / done flushes in particular
+// (256 B and 64 B pieces of a row per wave) sit in the L2 as partly written lines.  Same-box A/B (tools/ab.sh, kernel ms per pass):
+// CartPoleSwingUp 65 536 envs 0.2614 -> 0.2343 (observation stores alone: 0.2585), 131 072 envs 0.5718 -> 0.4618, CartPoleBalancing
+// 0.1477 -> 0.1305, InvertedPendulum 0.5328 -> 0.5175 (profiles/EXPERIMENTS.md).  Round 1 had tried the hint on the observation
+// stores alone and seen nothing.
+#ifndef EMEI_NT_STORES
+#define EMEI_NT_STORES 1  // 0: a variant build with plain output stores, for A/B runs
+#endif
+__device__ __forceinline__ void store16_stream(float4* p, const float4& v) {
+#if EMEI_NT_STORES
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (v4f_*)p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store16_stream(uint4* p, const uint4& v) {
+#if EMEI_NT_STORES
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    const v4u_ t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (v4u_*)p);
+#else
+    *p = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // trigonometry in the precision of the env.  Fast path: emei_math.h (straight-line, ~35 instructions);
 // the device library's Payne-Hanek sincos only repairs the (practically unreachable) |x| > 1e6 case,

@@ -336,10 +336,10 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
 #define EMEI_FLUSH_ROW(r) (r)
 #endif
     auto store_rew_rows = [&](int64_t row0, const float4& v) __attribute__((always_inline)) {
-        *(float4*)(a.reward_out + EMEI_FLUSH_ROW(row0) * n + rew_lane_off) = v;
+        store16_stream((float4*)(a.reward_out + EMEI_FLUSH_ROW(row0) * n + rew_lane_off), v);
     };
     auto store_done_rows = [&](int64_t row0, const uint4& v) __attribute__((always_inline)) {
-        if (kStage == 16 || lane < 4 * kStage) *(uint4*)(a.done_out + EMEI_FLUSH_ROW(row0) * n + done_lane_off) = v;  // kStage rows x 64 B
+        if (kStage == 16 || lane < 4 * kStage) store16_stream((uint4*)(a.done_out + EMEI_FLUSH_ROW(row0) * n + done_lane_off), v);  // kStage rows x 64 B
     };
 
     // Issue priority (Env::kRotatePriority: the InvertedPendulum kernels).  The SIMD's arbiter serves the OLDEST of its ready waves
@@ -406,7 +406,7 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
 #if defined(EMEI_EXP_OBS_ROW0)  // experiment (timing only): the observation stores alternate between rows 0 and 1 — the same instructions, no HBM write stream
                 (a.obs_out + (int64_t)((t0 + j) & 1) * n)[li] = obs4;
 #else
-                (a.obs_out + (int64_t)(t0 + j) * n)[li] = obs4;
+                store16_stream(a.obs_out + (int64_t)(t0 + j) * n + li, obs4);
 #endif
                 store_obs_peers(t0 + j, obs4);
                 if (q == 0) {  // rows staged during the previous group: their LDS read has landed
