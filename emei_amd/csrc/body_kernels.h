@@ -16,6 +16,7 @@
 //   batch_reward(obs, pre_obs, act, m, freq_rate) / batch_terminal(obs, m)   // stateless, float32 or float64 rows
 //   kHasCtrlCost, ctrl_cost(act)                    // the reward has a control-cost term w_ctrl * sum a^2 (whole-batch quirk mode)
 //   kSpareReset                                     // episodes end per lane (terminal states): keep a spare init state
+//   kStreamOutputs                                  // per-step outputs leave with the non-temporal hint (emei_device.h:store_body_out)
 //   kMinWavesPerEU                                  // register cap of the rollout kernel (1 = none)
 //   park(s)                                         // state of the padding lanes of a ragged last wave
 //   kObsIsState                                     // the observation determines the state (get_batch_next_obs)
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
 #pragma unroll
                 for (int c = 0; c < kObsIt; ++c) {
                     const int vec = c * kWave + lane;
-                    if (vec < kObsVec) ((float4*)dst)[vec] = ((const float4*)obs_s[wv])[vec];
+                    if (vec < kObsVec) store_body_out<Body::kStreamOutputs>((float4*)dst + vec, ((const float4*)obs_s[wv])[vec]);
                 }
             } else {
                 for (int e = lane; e < wave_envs * NO; e += kWave) dst[e] = obs_s[wv][e];
@@ -483,8 +484,8 @@ __global__ void __launch_bounds__(rollout_block<Body>()) __attribute__((amdgpu_w
             wave_lds_fence();
         }
         if (active) {
-            if (a.reward_out) a.reward_out[(int64_t)t * n + i] = (float)rew;
-            if (a.done_out) a.done_out[(int64_t)t * n + i] = (uint8_t)done;
+            if (a.reward_out) store_body_out<Body::kStreamOutputs>(a.reward_out + (int64_t)t * n + i, (float)rew);
+            if (a.done_out) store_body_out<Body::kStreamOutputs>(a.done_out + (int64_t)t * n + i, (uint8_t)done);
         }
         EMEI_MARK(step_reset);
         if (__builtin_expect(auto_reset && __ballot(done != 0) != 0ull, 0)) {

@@ -1337,6 +1337,7 @@ struct CheetahBody {
     static constexpr bool kHasCtrlCost = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
+    static constexpr bool kStreamOutputs = false;  // emei_device.h:store_body_out
     static constexpr int NS = 18, NO = 18, NA = 6;
     static Model make_model(double dt, const EnvParams& ep) {
         Model m = cheetah::cheetah_make_model(dt);

@@ -94,6 +94,7 @@ struct DPendBody {
     static constexpr bool kHasCtrlCost = false;
     static constexpr bool kObsIsState = false;
     static constexpr bool kSpareReset = true;
+    static constexpr bool kStreamOutputs = true;  // emei_device.h:store_body_out
     static constexpr int NS = 6, NO = 6, NA = 1;
     static Model make_model(double dt, const EnvParams&) { return dpend::make_model(VARIANT >= 2, dt); }
 

@@ -954,6 +954,7 @@ struct HopperBody {
     static constexpr bool kHasCtrlCost = true;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = false;
+    static constexpr bool kStreamOutputs = false;  // emei_device.h:store_body_out
     static constexpr int NS = 12, NO = 12, NA = 3;
     static Model make_model(double dt, const EnvParams& ep) {
         Model m = hopper::make_model(dt);

@@ -65,6 +65,7 @@ struct InvPendBody {
     static constexpr bool kHasCtrlCost = false;
     static constexpr bool kObsIsState = true;
     static constexpr bool kSpareReset = true;
+    static constexpr bool kStreamOutputs = true;  // emei_device.h:store_body_out
     static constexpr int NS = 4, NO = 4, NA = 1;
     static Model make_model(double dt, const EnvParams&) { return ipend::make_model(VARIANT >= 2, dt); }
 
