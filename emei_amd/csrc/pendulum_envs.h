@@ -65,7 +65,7 @@ struct CartPole {
     static constexpr unsigned kSplitMaxRounds = EMEI_SPLIT_MAX_ROUNDS;
     static constexpr bool kXcdContiguous = true;  // pendulum_kernels.h: the env_block map of large shards
     static constexpr bool kPeerWrite = true;      // pendulum_kernels.h: pend_rollout_staged_peers_kernel is instantiated (emei_set_obs_peers)
-    static constexpr bool kTileBarrier = VARIANT == 0;  // pendulum_kernels.h: the block's waves meet once per tile (SwingUp; Balancing loses 4-5 %)
+    static constexpr bool kTileBarrier = false;   // pendulum_kernels.h: the block's waves meet once per tile — superseded by the non-temporal stores
     // Balancing under random actions: the pole falls within ~20 steps, some lane of a wave resets in 95 % of its env-steps
     // (SwingUp: 20 %) — the reset block in line (pendulum_kernels.h:maybe_reset)
     static constexpr bool kResetLikely = VARIANT == 1;

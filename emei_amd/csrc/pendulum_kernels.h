@@ -164,13 +164,12 @@ __global__ void __launch_bounds__(kBlock) pend_rollout_kernel(const RolloutArgs<
 //   obs     : already 16 B per lane, stored directly
 // => 1.31 vector stores + 1/16 loads per env-step instead of 3 stores + 1 load, and no 64 B
 // partial-line byte stores.  LDS slices are wave-private (LDS operations of one wave execute in
-// order), so no barrier is NEEDED anywhere; the one barrier of the SwingUp kernel (once per tile, Env::kTileBarrier) is there for the
-// memory system, not for correctness.
+// order), so there is no barrier anywhere (an optional one per tile, Env::kTileBarrier, is off: see its comment).
 // steps per staged tile: 16 for one-byte actions (1 KiB of LDS per wave and buffer); 8 for 4- and 8-byte actions, so that
 // the double-buffered tiles of a 256-thread block stay at 16 / 32 KiB and four blocks (with the other slices) fit a CU's
 // 160 KiB: config 3 runs 4 waves per SIMD
 #ifndef EMEI_TILE_BARRIER
-#define EMEI_TILE_BARRIER 1  // 0: a variant build without the per-tile block barrier of the staged kernel (Env::kTileBarrier), for A/B runs
+#define EMEI_TILE_BARRIER 1  // with Env::kTileBarrier: the per-tile block barrier of the staged kernel (A/B history: see its comment)
 #endif
 #ifndef EMEI_PRIO_ROTATE
 #define EMEI_PRIO_ROTATE 1  // 0: a variant build without the priority rotation of the staged kernel, for A/B runs
@@ -433,13 +432,11 @@ __device__ __forceinline__ void pend_rollout_staged(const RolloutArgs<Env>& a, c
         // checks the emitted immediate and the stores of the loop body in the shipped code object.
         static_assert(kTileWaitKeep == kStage && kTileWaitKeep < 64, "one unconditional obs store per staged step");
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kTileWaitKeep) : "memory");
-        // Env::kTileBarrier (CartPoleSwingUp): the four waves of a block meet here, once per tile.  They work on 256 neighbouring envs — 4 KiB of
-        // every output row — and otherwise drift apart; kept within a tile of each other their pieces of a row reach the memory system
-        // together.  Same-box A/B on five boxes: 65 536 envs 0.287-0.294 -> 0.260-0.267 ms on the three slow ones, 0.260 -> 0.263 on a fast
-        // one (the barrier evens the boxes out at the fast ones' time); 131 072 envs -5..-9 %, 524 288 -4 %, 1 048 576 -6..-11 %.  Meeting every
-        // 4 steps is no better.  CartPoleBalancing resets every ~15 steps (a spare redraw is ~150 instructions for the whole wave): its
-        // waves wait for each other instead, +4-5 % — not applied; nothing for the InvertedPendulum kernels (four waves per SIMD).
-        // Waves of a partial last block that returned above do not take part (the hardware counts the waves still alive).
+        // Env::kTileBarrier (no env sets it any more): the four waves of a block meet here, once per tile.  They work on 256 neighbouring
+        // envs — 4 KiB of every output row — and otherwise drift apart.  With plain output stores this was worth 7-11 % for CartPoleSwingUp
+        // on the slower boxes (0.287-0.294 -> 0.260-0.267 ms; nothing on the fast ones; CartPoleBalancing lost 4-5 % to the waiting).  The
+        // non-temporal stores (emei_device.h:store16_stream) remove what it worked around, and on top of them the barrier COSTS 3-4 %
+        // (0.2348 -> 0.2253 ms without it, 131 072 envs 0.4669 -> 0.4518): profiles/EXPERIMENTS.md.
         if constexpr (EMEI_TILE_BARRIER != 0 && Env::kTileBarrier) __builtin_amdgcn_s_barrier();
     }
     if (t0 > 0) {
